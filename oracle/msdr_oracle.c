@@ -1,0 +1,593 @@
+/*
+ * oracle/msdr_oracle.c -- CPU restatement of Minimal-SDR's per-block demodulation chain.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT (see msdr_oracle.h for who may load it and for the
+ * pinned / "parity unpinned" status of every function).  Written from the reference's
+ * arithmetic contract, not transcribed from its code: each function is the
+ * per-sample formula the cited lines implement.  Build: oracle/Makefile
+ * (gcc -O2 -ffp-contract=off -fwrapv -fno-strict-aliasing [-fopenmp]).
+ */
+#include "msdr_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static inline int32_t ssat16(int32_t v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
+static inline int32_t wrap_add32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+
+/* ======================================================================================
+ * A1  Minimal-SDR.ino:546-558  multiplication-free Fs/4 mixer.
+ * I = x*{1,0,-1,0}, Q = x*{0,1,0,-1}; the negate is formed in int and narrowed to int16,
+ * so -(-32768) stays -32768.  A block always starts at n = 0 (mod 4) (B = 128).
+ * ====================================================================================== */
+void orc_mix_fs4_q15(const int16_t *x, int16_t *I, int16_t *Q, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        int16_t neg = (int16_t)(uint16_t)(-(int32_t)x[i]);
+        switch (i & 3u) {
+        case 0: I[i] = x[i]; Q[i] = 0;    break;
+        case 1: I[i] = 0;    Q[i] = x[i]; break;
+        case 2: I[i] = neg;  Q[i] = 0;    break;
+        default: I[i] = 0;   Q[i] = neg;  break;
+        }
+    }
+}
+
+/* ======================================================================================
+ * A2  freq_conv.cpp:30-116.  The three vector ops are CMSIS-DSP V1.5.x functions whose
+ * sources are NOT in the reference (un-vendored; Teensyduino ships them prebuilt).  Their
+ * published definitions: mult = sat16((a*b)>>15), add/sub = sat16(a +/- b).
+ * ====================================================================================== */
+void orc_mult_q15(const q15_t *a, const q15_t *b, q15_t *dst, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++) dst[i] = (q15_t)ssat16(((int32_t)a[i] * b[i]) >> 15);
+}
+void orc_add_q15(const q15_t *a, const q15_t *b, q15_t *dst, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++) dst[i] = (q15_t)ssat16((int32_t)a[i] + b[i]);
+}
+void orc_sub_q15(const q15_t *a, const q15_t *b, q15_t *dst, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++) dst[i] = (q15_t)ssat16((int32_t)a[i] - b[i]);
+}
+
+/* `pass` is inverted in the reference: pass == 0 forwards the inputs untouched
+ * (freq_conv.cpp:49-56), the default pass(1) processes (freq_conv.h:39).
+ * dir == 0 (:67-84):  I' = I*oq + Q*oi,  Q' = Q*oq - I*oi
+ * dir == 1 (:86-103): Q' = Q*oq + I*oi,  I' = I*oq - Q*oi
+ * All four products are formed from the ORIGINAL I,Q before either is overwritten. */
+void orc_freqconv_q15(q15_t *I, q15_t *Q, const q15_t *osc_i, const q15_t *osc_q,
+                      int dir, int pass, uint32_t n)
+{
+    if (!pass) return;
+    for (uint32_t i = 0; i < n; i++) {
+        int32_t Ioq = ssat16(((int32_t)I[i] * osc_q[i]) >> 15);
+        int32_t Ioi = ssat16(((int32_t)I[i] * osc_i[i]) >> 15);
+        int32_t Qoq = ssat16(((int32_t)Q[i] * osc_q[i]) >> 15);
+        int32_t Qoi = ssat16(((int32_t)Q[i] * osc_i[i]) >> 15);
+        if (!dir) { I[i] = (q15_t)ssat16(Ioq + Qoi); Q[i] = (q15_t)ssat16(Qoq - Ioi); }
+        else      { Q[i] = (q15_t)ssat16(Qoq + Ioi); I[i] = (q15_t)ssat16(Ioq - Qoi); }
+    }
+}
+void orc_freqconv_f32(float *I, float *Q, const float *osc_i, const float *osc_q,
+                      int dir, int pass, uint32_t n)
+{
+    if (!pass) return;
+    for (uint32_t i = 0; i < n; i++) {
+        float Ioq = I[i] * osc_q[i], Ioi = I[i] * osc_i[i];
+        float Qoq = Q[i] * osc_q[i], Qoi = Q[i] * osc_i[i];
+        if (!dir) { I[i] = Ioq + Qoi; Q[i] = Qoq - Ioi; }
+        else      { Q[i] = Qoq + Ioi; I[i] = Ioq - Qoi; }
+    }
+}
+
+/* ======================================================================================
+ * A3  arm_fir_init_q15.c:78-138 (Cortex-M4 branch): odd numTaps is an argument error
+ * (:93-96), state of numTaps+blockSize elements is cleared (:106).
+ * ====================================================================================== */
+int orc_fir_init_q15(orc_fir_instance_q15 *S, uint16_t numTaps, const q15_t *pCoeffs,
+                     q15_t *pState, uint32_t blockSize)
+{
+    if (numTaps & 1u) return ORC_ARGUMENT_ERROR;
+    S->numTaps = numTaps;
+    S->pCoeffs = pCoeffs;
+    memset(pState, 0, ((size_t)numTaps + blockSize) * sizeof(q15_t));
+    S->pState = pState;
+    return ORC_SUCCESS;
+}
+
+/* ======================================================================================
+ * A4  arm_fir_fast_q15.c:60-329.
+ *   y[n] = sat16( wrap32( sum_{k=0}^{N-1} pCoeffs[k] * w[n+k] ) >> 15 ),
+ * w = [N-1 history samples | the block].  32-bit WRAPPING accumulator (doc :49-53),
+ * arithmetic shift, saturate on store (:234-238, :287); tail of the window is carried to
+ * the front of pState for the next call (:296-327).
+ * ====================================================================================== */
+void orc_fir_fast_q15(const orc_fir_instance_q15 *S, const q15_t *pSrc, q15_t *pDst,
+                      uint32_t blockSize)
+{
+    const uint32_t N = S->numTaps;
+    q15_t *w = S->pState;
+    memcpy(w + (N - 1), pSrc, blockSize * sizeof(q15_t));
+    for (uint32_t n = 0; n < blockSize; n++) {
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < N; k++)
+            acc += (uint32_t)((int32_t)S->pCoeffs[k] * (int32_t)w[n + k]);
+        pDst[n] = (q15_t)ssat16(((int32_t)acc) >> 15);
+    }
+    memmove(w, w + blockSize, (N - 1) * sizeof(q15_t));
+}
+
+void orc_copy_q15(const q15_t *src, q15_t *dst, uint32_t n) { memmove(dst, src, n * sizeof(q15_t)); }
+
+/* ======================================================================================
+ * arm_sqrt_q31.c:50-138  Newton inverse-sqrt in Q31 (Teensy 3.2 AM branch).
+ * ====================================================================================== */
+int orc_sqrt_q31(q31_t in, q31_t *out)
+{
+    if (in <= 0) { *out = 0; return ORC_ARGUMENT_ERROR; }
+    int32_t number = in;
+    int32_t sign_bits = (int32_t)(uint8_t)__builtin_clz((uint32_t)number) - 1;
+    int32_t sh = (sign_bits % 2 == 0) ? sign_bits : sign_bits - 1;
+    number = (int32_t)((uint32_t)number << sh);
+    int32_t half = number >> 1, temp1 = number;
+    union { int32_t i; float f; } cv;
+    cv.f = (float)number * 4.6566128731e-010f;
+    cv.i = 0x5f3759df - (cv.i >> 1);
+    int32_t var1 = (int32_t)(cv.f * 1073741824);
+    for (int it = 0; it < 3; it++) {
+        int32_t sq = (int32_t)(((int64_t)var1 * var1) >> 31);
+        int32_t t  = (int32_t)(((int64_t)sq * (int64_t)half) >> 31);
+        var1 = (int32_t)((uint32_t)((int32_t)(((int64_t)var1 * (0x30000000 - t)) >> 31)) << 2);
+    }
+    var1 = (int32_t)((uint32_t)((int32_t)(((int64_t)temp1 * var1) >> 31)) << 1);
+    *out = var1 >> (sh / 2);
+    return ORC_SUCCESS;
+}
+
+/* ======================================================================================
+ * A5  Minimal-SDR.ino:589-691.
+ *  LSB :591-596  (int16)(I - Q)      USB :598-604  (int16)(I + Q)   -- truncating store
+ *  AM/CW T3.6 :607-616  (int16)trunc(sqrtf((float)(I*I + Q*Q))), sum formed in int32
+ *             (arm_sqrt_f32 returns 0 for negative input, arm_math.h:5733-5758)
+ *  AM/CW T3.2 :618-627  arm_sqrt_q31(I*I+Q*Q) >> 16
+ * Out-of-range float->int16 (only reachable with |I|,|Q| > 23170 together) is taken as
+ * convert-to-int32-then-truncate, which is what both ARM (vcvt + strh) and x86 do.
+ * ====================================================================================== */
+void orc_demod_q15(int mode, int sqrt_kind, const int16_t *I, const int16_t *Q,
+                   int16_t *out, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        int32_t a = I[i], b = Q[i];
+        switch (mode) {
+        case ORC_LSB: out[i] = (int16_t)(uint16_t)(uint32_t)(a - b); break;
+        case ORC_USB: out[i] = (int16_t)(uint16_t)(uint32_t)(a + b); break;
+        default: {
+            int32_t s = wrap_add32(a * a, b * b);
+            if (sqrt_kind == ORC_SQRT_Q31) {
+                q31_t r; orc_sqrt_q31(s, &r);
+                out[i] = (int16_t)(r >> 16);
+            } else {
+                float f = (float)s;
+                float r = (f >= 0.0f) ? sqrtf(f) : 0.0f;
+                out[i] = (int16_t)(uint16_t)(uint32_t)(int32_t)r;
+            }
+        } break;
+        }
+    }
+}
+void orc_demod_f32(int mode, const float *I, const float *Q, float *out, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        switch (mode) {
+        case ORC_LSB: out[i] = I[i] - Q[i]; break;
+        case ORC_USB: out[i] = I[i] + Q[i]; break;
+        default:      out[i] = sqrtf(I[i] * I[i] + Q[i] * Q[i]); break;
+        }
+    }
+}
+
+/* ======================================================================================
+ * A6  arm_fir_f32 -- CMSIS-DSP V1.5.x, source NOT in the reference (prototype
+ * arm_math.h:1182-1186, init :1197-1202, instance :1047-1052).  Published algorithm:
+ * y[n] = sum_k pCoeffs[k]*pState[n+k], pState = [N-1 history | block], each output
+ * accumulated from 0 in ascending k, separate multiply and add.   PARITY UNPINNED.
+ * ====================================================================================== */
+void orc_fir_init_f32(orc_fir_instance_f32 *S, uint16_t numTaps, const float *pCoeffs,
+                      float *pState, uint32_t blockSize)
+{
+    S->numTaps = numTaps; S->pCoeffs = pCoeffs; S->pState = pState;
+    memset(pState, 0, ((size_t)numTaps + blockSize - 1u) * sizeof(float));
+}
+void orc_fir_f32(const orc_fir_instance_f32 *S, const float *pSrc, float *pDst,
+                 uint32_t blockSize)
+{
+    const uint32_t N = S->numTaps;
+    float *w = S->pState;
+    memcpy(w + (N - 1), pSrc, blockSize * sizeof(float));
+    for (uint32_t n = 0; n < blockSize; n++) {
+        float acc = 0.0f;
+        for (uint32_t k = 0; k < N; k++) acc += w[n + k] * S->pCoeffs[k];
+        pDst[n] = acc;
+    }
+    memmove(w, w + blockSize, (N - 1) * sizeof(float));
+}
+
+/* ======================================================================================
+ * A7  src/Audio/filter_biquad.cpp:33-100 with src/Audio/utility/dspinst.h:34-51,235-249.
+ * Stage record = 8 words {b0,b1,b2,-a1,-a2, x[n-1]:x[n-2], y[n-1]:y[n-2], residue|flag}.
+ * Per sample:  acc = residue + sum of five (coef * s16) >> 16   (top 32 of the 48-bit
+ * product, i.e. smlawb/smlawt; 32-bit wrapping adds), y = ssat16(acc >> 14),
+ * residue = acc & 0x3FFF (first-order error feedback).  Stages run one after another over
+ * the whole block; bit 31 of word 7 says another stage follows.   PARITY UNPINNED.
+ * ====================================================================================== */
+static inline int32_t mulw16(int32_t coef, int16_t s) { return (int32_t)(((int64_t)coef * s) >> 16); }
+
+void orc_biquad_teensy_init(orc_biquad_teensy *b) { memset(b->definition, 0, sizeof b->definition); }
+
+void orc_biquad_teensy_set_coefficients(orc_biquad_teensy *b, uint32_t stage, const int32_t coef[5])
+{
+    if (stage >= 4) return;                                   /* cpp:86 */
+    int32_t *d = b->definition + (stage << 3);
+    if (stage > 0) d[-1] = (int32_t)((uint32_t)d[-1] | 0x80000000u);  /* cpp:89 */
+    d[0] = coef[0]; d[1] = coef[1]; d[2] = coef[2];
+    d[3] = (int32_t)(0u - (uint32_t)coef[3]);                 /* cpp:93-94: stored negated */
+    d[4] = (int32_t)(0u - (uint32_t)coef[4]);
+    /* words 5,6 (history) are deliberately kept (cpp:95-97) */
+    d[7] = (int32_t)((uint32_t)d[7] & 0x80000000u);           /* cpp:98 */
+}
+
+void orc_biquad_teensy_update(orc_biquad_teensy *b, int16_t *data, uint32_t n)
+{
+    int32_t *st = b->definition;
+    uint32_t flag;
+    do {
+        const int32_t b0 = st[0], b1 = st[1], b2 = st[2], a1 = st[3], a2 = st[4];
+        int16_t x1 = (int16_t)((uint32_t)st[5] >> 16), x2 = (int16_t)(st[5] & 0xFFFF);
+        int16_t y1 = (int16_t)((uint32_t)st[6] >> 16), y2 = (int16_t)(st[6] & 0xFFFF);
+        int32_t res = st[7] & 0x3FFF;
+        for (uint32_t i = 0; i < n; i++) {
+            int16_t x0 = data[i];
+            int32_t acc = res;
+            acc = wrap_add32(acc, mulw16(b0, x0));
+            acc = wrap_add32(acc, mulw16(b1, x1));
+            acc = wrap_add32(acc, mulw16(b2, x2));
+            acc = wrap_add32(acc, mulw16(a1, y1));
+            acc = wrap_add32(acc, mulw16(a2, y2));
+            int16_t y0 = (int16_t)ssat16(acc >> 14);
+            res = acc & 0x3FFF;
+            x2 = x1; x1 = x0; y2 = y1; y1 = y0;
+            data[i] = y0;
+        }
+        flag = (uint32_t)st[7] & 0x80000000u;
+        st[5] = (int32_t)(((uint32_t)(uint16_t)x1 << 16) | (uint16_t)x2);
+        st[6] = (int32_t)(((uint32_t)(uint16_t)y1 << 16) | (uint16_t)y2);
+        st[7] = (int32_t)((uint32_t)res | flag);
+        st += 8;
+    } while (flag);
+}
+
+/* filter_biquad.h:56-149 -- Audio-EQ-cookbook designers; coefficients scaled by 2^30 and
+ * truncated to int; a1,a2 in textbook sign (negated later by setCoefficients). */
+void orc_biquad_design(int kind, float frequency, float q_or_gain, float slope,
+                       double sample_rate, int32_t coef[5])
+{
+    double w0 = frequency * (2 * 3.141592654 / sample_rate);
+    double sinW0 = sin(w0), cosW0 = cos(w0);
+    if (kind <= ORC_BQ_NOTCH) {
+        double alpha = sinW0 / ((double)q_or_gain * 2.0);
+        double scale = 1073741824.0 / (1.0 + alpha);
+        switch (kind) {
+        case ORC_BQ_LOWPASS:
+            coef[0] = (int32_t)(((1.0 - cosW0) / 2.0) * scale);
+            coef[1] = (int32_t)((1.0 - cosW0) * scale);
+            coef[2] = coef[0];
+            break;
+        case ORC_BQ_HIGHPASS:
+            coef[0] = (int32_t)(((1.0 + cosW0) / 2.0) * scale);
+            coef[1] = (int32_t)(-(1.0 + cosW0) * scale);
+            coef[2] = coef[0];
+            break;
+        case ORC_BQ_BANDPASS:
+            coef[0] = (int32_t)(alpha * scale);
+            coef[1] = 0;
+            coef[2] = (int32_t)((-alpha) * scale);
+            break;
+        default: /* notch */
+            coef[0] = (int32_t)scale;
+            coef[1] = (int32_t)((-2.0 * cosW0) * scale);
+            coef[2] = coef[0];
+            break;
+        }
+        coef[3] = (int32_t)((-2.0 * cosW0) * scale);
+        coef[4] = (int32_t)((1.0 - alpha) * scale);
+        return;
+    }
+    double a = pow(10.0, q_or_gain / 40.0);
+    double sinsq = sinW0 * sqrt((pow(a, 2.0) + 1.0) * (1.0 / slope - 1.0) + 2.0 * a);
+    double aMinus = (a - 1.0) * cosW0, aPlus = (a + 1.0) * cosW0;
+    if (kind == ORC_BQ_LOWSHELF) {
+        double scale = 1073741824.0 / ((a + 1.0) + aMinus + sinsq);
+        coef[0] = (int32_t)(a * ((a + 1.0) - aMinus + sinsq) * scale);
+        coef[1] = (int32_t)(2.0 * a * ((a - 1.0) - aPlus) * scale);
+        coef[2] = (int32_t)(a * ((a + 1.0) - aMinus - sinsq) * scale);
+        coef[3] = (int32_t)(-2.0 * ((a - 1.0) + aPlus) * scale);
+        coef[4] = (int32_t)(((a + 1.0) + aMinus - sinsq) * scale);
+    } else {
+        double scale = 1073741824.0 / ((a + 1.0) - aMinus + sinsq);
+        coef[0] = (int32_t)(a * ((a + 1.0) + aMinus + sinsq) * scale);
+        coef[1] = (int32_t)(-2.0 * a * ((a - 1.0) + aPlus) * scale);
+        coef[2] = (int32_t)(a * ((a + 1.0) + aMinus - sinsq) * scale);
+        coef[3] = (int32_t)(2.0 * ((a - 1.0) - aPlus) * scale);
+        coef[4] = (int32_t)(((a + 1.0) - aMinus - sinsq) * scale);
+    }
+}
+
+/* ======================================================================================
+ * A8  arm_biquad_cascade_df1_f32 -- CMSIS-DSP V1.5.x, source NOT in the reference
+ * (prototype arm_math.h:1333-1337, init :1347-1351, instance :1230-1235).  Published
+ * algorithm: y = b0*x + b1*x1 + b2*x2 + a1*y1 + a2*y2 evaluated left to right, feedback
+ * terms ADDED (caller passes -a1,-a2 of the textbook form); stage s feeds stage s+1;
+ * state per stage {x1,x2,y1,y2}.   PARITY UNPINNED.
+ * ====================================================================================== */
+void orc_biquad_df1_init_f32(orc_biquad_df1_f32 *S, uint8_t numStages, const float *pCoeffs,
+                             float *pState)
+{
+    S->numStages = numStages; S->pCoeffs = pCoeffs; S->pState = pState;
+    memset(pState, 0, 4u * numStages * sizeof(float));
+}
+void orc_biquad_df1_f32_run(const orc_biquad_df1_f32 *S, const float *pSrc, float *pDst,
+                            uint32_t blockSize)
+{
+    const float *in = pSrc;
+    for (uint32_t s = 0; s < S->numStages; s++) {
+        const float *c = S->pCoeffs + 5 * s;
+        float *st = S->pState + 4 * s;
+        float x1 = st[0], x2 = st[1], y1 = st[2], y2 = st[3];
+        for (uint32_t i = 0; i < blockSize; i++) {
+            float x0 = in[i];
+            float y0 = (c[0] * x0) + (c[1] * x1) + (c[2] * x2) + (c[3] * y1) + (c[4] * y2);
+            x2 = x1; x1 = x0; y2 = y1; y1 = y0;
+            pDst[i] = y0;
+        }
+        st[0] = x1; st[1] = x2; st[2] = y1; st[3] = y2;
+        in = pDst;
+    }
+    if (S->numStages == 0 && pDst != pSrc) memcpy(pDst, pSrc, blockSize * sizeof(float));
+}
+
+/* ======================================================================================
+ * A9  Minimal-SDR.ino:782-899  Kaiser-window FIR designer.  Operand types are kept exactly
+ * (float vs double per C promotion rules in the sketch) because the result is truncated to
+ * int16.  `PI`: arm_math.h:365-367 gives the float fallback 3.14159265358979f; on a Teensy
+ * Arduino.h (un-vendored) supplies a double literal first.  orc_set_pi_double(1) selects the
+ * latter; default is the float fallback (what the vendored sources alone give; both agree
+ * on every tap set in tests/golden).
+ * ====================================================================================== */
+static int g_pi_double = 0;
+void orc_set_pi_double(int on) { g_pi_double = on; }
+#define PI_F 3.14159265358979f
+#define PI_D 3.1415926535897932384626433832795
+
+float orc_izero(float x)
+{
+    static const float errorlimit = 1e-9;
+    float x2 = x / 2.0;
+    float summe = 1.0, ds = 1.0, di = 1.0, tmp;
+    do {
+        tmp = x2 / di;
+        tmp *= tmp;
+        ds *= tmp;
+        summe += ds;
+        di += 1.0;
+    } while (ds >= errorlimit * summe);
+    return summe;
+}
+
+float orc_m_sinc(int m, float fc)
+{
+    if (m == 0) return 1.0f;
+    float x = g_pi_double ? (float)(m * (PI_D / 2)) : (m * (PI_F / 2));
+    return sinf(x * fc) / (fc * x);
+}
+
+static float pih_times(int k, float fc) /* PIH * k * fc, :862,:866 */
+{
+    return g_pi_double ? (float)((PI_D / 2) * k * fc) : ((PI_F / 2) * k * fc);
+}
+
+void orc_calc_fir_coeffs(int16_t *coeffs, int numCoeffs, float fc, float Astop, int type,
+                         float dfc, float Fsamprate)
+{
+    int ii, jj;
+    float Beta, izb, fcf = fc;
+    int nc = numCoeffs;
+    fc = fc / Fsamprate;
+    dfc = dfc / Fsamprate;
+    if (Astop < 20.96) Beta = 0.0;                                          /* :801-806 */
+    else if (Astop >= 50.0) Beta = 0.1102 * (Astop - 8.71);
+    else Beta = 0.5842 * powf((float)(Astop - 20.96), (float)0.4) + 0.07886 * (Astop - 20.96);
+    izb = orc_izero(Beta);
+    switch (type) {
+    case 0: fcf = fc * 2.0; nc = numCoeffs; break;                          /* :812-815 */
+    case 1: fcf = -fc; nc = 2 * (numCoeffs / 2); break;
+    case 2:
+    case 3: fcf = dfc; nc = 2 * (numCoeffs / 2); break;
+    case 4: {                                                               /* :828-845 */
+        nc = 2 * (numCoeffs / 2);
+        for (ii = 0; ii < 2 * (nc - 1); ii++) coeffs[ii] = 0;
+        coeffs[nc] = 1;
+        for (ii = 1; ii < (nc + 1); ii += 2) {
+            if (2 * ii == nc) continue;
+            float x = (float)(2 * ii - nc) / (float)nc;
+            float w = orc_izero(Beta * sqrtf(1.0f - x * x)) / izb;
+            if (g_pi_double)
+                coeffs[2 * ii + 1] = (int16_t)(int32_t)(32767 * (1.0f / ((PI_D / 2) * (float)(ii - nc / 2)) * w));
+            else
+                coeffs[2 * ii + 1] = (int16_t)(int32_t)(32767 * (1.0f / ((PI_F / 2) * (float)(ii - nc / 2)) * w));
+        }
+        return;
+    }
+    default: return;
+    }
+    for (ii = -nc, jj = 0; ii < nc; ii += 2, jj++) {                         /* :850-855 */
+        float x = (float)ii / (float)nc;
+        float w = orc_izero(Beta * sqrtf(1.0f - x * x)) / izb;
+        coeffs[jj] = (int16_t)(int32_t)(fcf * orc_m_sinc(ii, fcf) * w * 32767);
+    }
+    switch (type) {                                                          /* :857-871 */
+    case 1: coeffs[nc / 2] += 1; break;
+    case 2:
+        for (jj = 0; jj < nc + 1; jj++)
+            coeffs[jj] = (int16_t)(int32_t)(coeffs[jj] * (2.0f * cosf(pih_times(2 * jj - nc, fc))));
+        break;
+    case 3:
+        for (jj = 0; jj < nc + 1; jj++)
+            coeffs[jj] = (int16_t)(int32_t)(coeffs[jj] * (-2.0f * cosf(pih_times(2 * jj - nc, fc))));
+        coeffs[nc / 2] += 1;
+        break;
+    }
+}
+
+/* ======================================================================================
+ * Whole chain, q15: demodulation() Minimal-SDR.ino:518-775 (mix :546-558, FIR pair
+ * :574-575, copy :577-578, demod :589-691) followed by the AudioFilterBiquad nodes wired
+ * after queue_dac (.ino:77-81), one update() per block each.
+ * mixer == 1 substitutes the AudioEffectFreqConv node (A2) fed with the real IF on port 0,
+ * zeros on port 1, dir = 1  =>  I = x*osc_q, Q = x*osc_i.
+ * ====================================================================================== */
+void orc_chain_q15(const orc_chain_q15_cfg *cfg, orc_chain_q15_state *st, const int16_t *x,
+                   int16_t *audio, int16_t *i_out, int16_t *q_out, uint32_t n_blocks)
+{
+    orc_fir_instance_q15 FI = { (uint16_t)cfg->num_taps, st->state_i, cfg->coeffs_i };
+    orc_fir_instance_q15 FQ = { (uint16_t)cfg->num_taps, st->state_q, cfg->coeffs_q };
+    int16_t I[ORC_BLOCK], Q[ORC_BLOCK], If[ORC_BLOCK], Qf[ORC_BLOCK];
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        const int16_t *xb = x + (size_t)b * ORC_BLOCK;
+        int16_t *ab = audio + (size_t)b * ORC_BLOCK;
+        if (cfg->mixer == 0) {
+            orc_mix_fs4_q15(xb, I, Q, ORC_BLOCK);
+        } else {
+            memcpy(I, xb, sizeof I);
+            memset(Q, 0, sizeof Q);
+            orc_freqconv_q15(I, Q, cfg->osc_i, cfg->osc_q, 1, 1, ORC_BLOCK);
+        }
+        orc_fir_fast_q15(&FI, I, If, ORC_BLOCK);
+        orc_fir_fast_q15(&FQ, Q, Qf, ORC_BLOCK);
+        if (i_out) memcpy(i_out + (size_t)b * ORC_BLOCK, If, sizeof If);
+        if (q_out) memcpy(q_out + (size_t)b * ORC_BLOCK, Qf, sizeof Qf);
+        orc_demod_q15(cfg->mode, cfg->sqrt_kind, If, Qf, ab, ORC_BLOCK);
+        for (uint32_t k = 0; k < cfg->n_biquad_nodes; k++)
+            orc_biquad_teensy_update(&st->bq[k], ab, ORC_BLOCK);
+    }
+}
+
+/* ======================================================================================
+ * Whole chain, fp32 (the north-star flavour): int16 IF -> float (x * in_scale) ->
+ * NCO mix I = x*osc_q[n % P], Q = x*osc_i[n % P] (freq_conv dir=1, Q-in = 0, in fp32) ->
+ * arm_fir_f32 pair (A6) -> demod (A5 in fp32) -> arm_biquad_cascade_df1_f32 (A8).
+ * Sample-sequential; every product and sum is a separately rounded fp32 operation.
+ * ====================================================================================== */
+void orc_chain_f32(const orc_chain_f32_cfg *cfg, orc_chain_f32_state *st, const int16_t *x,
+                   float *audio, uint64_t n)
+{
+    const uint32_t N = cfg->num_taps, H = N - 1;
+    /* circular-free sliding window: keep 2 copies so a window is always contiguous */
+    const uint32_t CH = 4096;
+    float *wi = (float *)malloc((size_t)(H + CH) * sizeof(float));
+    float *wq = (float *)malloc((size_t)(H + CH) * sizeof(float));
+    memcpy(wi, st->hist_i, H * sizeof(float));
+    memcpy(wq, st->hist_q, H * sizeof(float));
+    float *bs = st->bq_state;
+    for (uint64_t base = 0; base < n; base += CH) {
+        uint32_t len = (uint32_t)((n - base < CH) ? (n - base) : CH);
+        for (uint32_t i = 0; i < len; i++) {
+            float xf = (float)x[base + i] * cfg->in_scale;
+            uint32_t ph = (uint32_t)((st->n0 + base + i) % cfg->osc_len);
+            wi[H + i] = xf * cfg->osc_q[ph];
+            wq[H + i] = xf * cfg->osc_i[ph];
+        }
+        for (uint32_t i = 0; i < len; i++) {
+            float ai = 0.0f, aq = 0.0f;
+            for (uint32_t k = 0; k < N; k++) {
+                ai += wi[i + k] * cfg->coeffs_i[k];
+                aq += wq[i + k] * cfg->coeffs_q[k];
+            }
+            float d;
+            switch (cfg->mode) {
+            case ORC_LSB: d = ai - aq; break;
+            case ORC_USB: d = ai + aq; break;
+            default:      d = sqrtf(ai * ai + aq * aq); break;
+            }
+            for (uint32_t s = 0; s < cfg->num_stages; s++) {
+                const float *c = cfg->bq_coeffs + 5 * s;
+                float *q = bs + 4 * s;
+                float y = (c[0] * d) + (c[1] * q[0]) + (c[2] * q[1]) + (c[3] * q[2]) + (c[4] * q[3]);
+                q[1] = q[0]; q[0] = d; q[3] = q[2]; q[2] = y;
+                d = y;
+            }
+            audio[base + i] = d;
+        }
+        memmove(wi, wi + len, H * sizeof(float));
+        memmove(wq, wq + len, H * sizeof(float));
+    }
+    memcpy(st->hist_i, wi, H * sizeof(float));
+    memcpy(st->hist_q, wq, H * sizeof(float));
+    st->n0 += n;
+    free(wi); free(wq);
+}
+
+int orc_chain_f32_batch(const orc_chain_f32_cfg *cfg, const int32_t *mode_per_channel,
+                        const int16_t *x, float *audio, uint32_t channels, uint64_t n,
+                        int threads)
+{
+    int used = 1;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    used = threads > 0 ? threads : omp_get_max_threads();
+#endif
+    const uint32_t H = cfg->num_taps - 1;
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < (int64_t)channels; c++) {
+        orc_chain_f32_cfg lc = *cfg;
+        if (mode_per_channel) lc.mode = mode_per_channel[c];
+        orc_chain_f32_state st;
+        st.hist_i = (float *)calloc(H ? H : 1, sizeof(float));
+        st.hist_q = (float *)calloc(H ? H : 1, sizeof(float));
+        memset(st.bq_state, 0, sizeof st.bq_state);
+        st.n0 = 0;
+        orc_chain_f32(&lc, &st, x + (size_t)c * n, audio + (size_t)c * n, n);
+        free(st.hist_i); free(st.hist_q);
+    }
+    return used;
+}
+
+int orc_chain_q15_batch(const orc_chain_q15_cfg *cfg, const int32_t *mode_per_channel,
+                        const int16_t *x, int16_t *audio, uint32_t channels,
+                        uint32_t n_blocks, int threads)
+{
+    int used = 1;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    used = threads > 0 ? threads : omp_get_max_threads();
+#endif
+    const size_t n = (size_t)n_blocks * ORC_BLOCK;
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < (int64_t)channels; c++) {
+        orc_chain_q15_cfg lc = *cfg;
+        if (mode_per_channel) lc.mode = mode_per_channel[c];
+        orc_chain_q15_state st;
+        st.state_i = (q15_t *)calloc(cfg->num_taps + ORC_BLOCK, sizeof(q15_t));
+        st.state_q = (q15_t *)calloc(cfg->num_taps + ORC_BLOCK, sizeof(q15_t));
+        for (uint32_t k = 0; k < 2; k++) {
+            if (k < cfg->n_biquad_nodes && cfg->bq_init) st.bq[k] = cfg->bq_init[k];
+            else orc_biquad_teensy_init(&st.bq[k]);
+        }
+        orc_chain_q15(&lc, &st, x + c * n, audio + c * n, NULL, NULL, n_blocks);
+        free(st.state_i); free(st.state_q);
+    }
+    return used;
+}

@@ -1,0 +1,169 @@
+/*
+ * oracle/msdr_oracle.h -- CPU restatement of Minimal-SDR's per-block demodulation chain.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py may load this library; the product path
+ * (minimal-sdr_amd/, include/msdr.h) never links, loads or calls it.
+ *
+ * Every function cites the reference file:line (relative to /root/reference) it restates.
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   PINNED   against oracle/_ref/libmsdr_ref.so (the reference's own sources compiled here by
+ *            oracle/build_ref.sh): orc_fir_init_q15, orc_fir_fast_q15, orc_copy_q15,
+ *            orc_sqrt_q31, orc_calc_fir_coeffs, orc_izero, orc_m_sinc.
+ *   UNPINNED ("parity unpinned": the reference code cannot be built here without stand-ins for
+ *            the un-vendored Teensyduino core / ARM inline asm, or has no source at all):
+ *            orc_mix_fs4_q15, orc_freqconv_q15 (+ orc_mult/add/sub_q15), orc_demod_q15,
+ *            orc_biquad_teensy_*, and every *_f32 function (arm_fir_f32 and
+ *            arm_biquad_cascade_df1_f32 are prototypes only in the reference:
+ *            src/CMSIS_5/arm_math.h:1182-1202, :1333-1351; module CMSIS-DSP V1.5.x).
+ */
+#ifndef MSDR_ORACLE_H
+#define MSDR_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int16_t q15_t;
+typedef int32_t q31_t;
+
+/* stations.h:4  enum { SYNCAM, AM, LSB, USB, CW } */
+enum { ORC_SYNCAM = 0, ORC_AM = 1, ORC_LSB = 2, ORC_USB = 3, ORC_CW = 4 };
+/* which square root the AM/CW branch uses: Minimal-SDR.ino:606-616 (T3.6, sqrtf) or :618-627 (T3.2, arm_sqrt_q31) */
+enum { ORC_SQRT_F32 = 0, ORC_SQRT_Q31 = 1 };
+/* arm_math.h:404-413 */
+enum { ORC_SUCCESS = 0, ORC_ARGUMENT_ERROR = -1 };
+
+#define ORC_BLOCK 128 /* AUDIO_BLOCK_SAMPLES, Teensy core default; used e.g. Minimal-SDR.ino:525 */
+
+/* ---- A1: Fs/4 I/Q mixer, Minimal-SDR.ino:546-558 ------------------------------------- */
+void orc_mix_fs4_q15(const int16_t *x, int16_t *I, int16_t *Q, uint32_t n);
+
+/* ---- A2: freq_conv.cpp:30-116 (arithmetic = CMSIS-DSP 1.5.x arm_mult/add/sub_q15) ------ */
+void orc_mult_q15(const q15_t *a, const q15_t *b, q15_t *dst, uint32_t n);
+void orc_add_q15(const q15_t *a, const q15_t *b, q15_t *dst, uint32_t n);
+void orc_sub_q15(const q15_t *a, const q15_t *b, q15_t *dst, uint32_t n);
+/* in place on I,Q like the node; osc_i = Osc_I_buffer_i ("sin"), osc_q = Osc_Q_buffer_i ("cos") */
+void orc_freqconv_q15(q15_t *I, q15_t *Q, const q15_t *osc_i, const q15_t *osc_q,
+                      int dir, int pass, uint32_t n);
+void orc_freqconv_f32(float *I, float *Q, const float *osc_i, const float *osc_q,
+                      int dir, int pass, uint32_t n);
+
+/* ---- A3/A4: arm_fir_init_q15.c:78-138, arm_fir_fast_q15.c:60-329 ----------------------- */
+typedef struct {
+    uint16_t numTaps;
+    q15_t *pState;        /* numTaps + blockSize elements (arm_fir_init_q15.c:106) */
+    const q15_t *pCoeffs; /* numTaps, "time reversed" storage (arm_fir_init_q15.c:51-54) */
+} orc_fir_instance_q15;
+int orc_fir_init_q15(orc_fir_instance_q15 *S, uint16_t numTaps, const q15_t *pCoeffs,
+                     q15_t *pState, uint32_t blockSize);
+void orc_fir_fast_q15(const orc_fir_instance_q15 *S, const q15_t *pSrc, q15_t *pDst,
+                      uint32_t blockSize);
+void orc_copy_q15(const q15_t *src, q15_t *dst, uint32_t n); /* arm_copy_q15.c:48-98 */
+
+/* ---- A5: demod switch, Minimal-SDR.ino:589-691 ------------------------------------------ */
+int orc_sqrt_q31(q31_t in, q31_t *out);                       /* arm_sqrt_q31.c:50-138 */
+void orc_demod_q15(int mode, int sqrt_kind, const int16_t *I, const int16_t *Q,
+                   int16_t *out, uint32_t n);
+void orc_demod_f32(int mode, const float *I, const float *Q, float *out, uint32_t n);
+
+/* ---- A6: arm_fir_f32 (CMSIS-DSP 1.5.x documented semantics; prototype arm_math.h:1182) -- */
+typedef struct {
+    uint16_t numTaps;
+    float *pState;        /* numTaps + blockSize - 1 (arm_math.h:1050) */
+    const float *pCoeffs;
+} orc_fir_instance_f32;
+void orc_fir_init_f32(orc_fir_instance_f32 *S, uint16_t numTaps, const float *pCoeffs,
+                      float *pState, uint32_t blockSize);
+void orc_fir_f32(const orc_fir_instance_f32 *S, const float *pSrc, float *pDst,
+                 uint32_t blockSize);
+
+/* ---- A7: Teensy AudioFilterBiquad, src/Audio/filter_biquad.cpp:33-100, filter_biquad.h --- */
+typedef struct orc_biquad_teensy_s { int32_t definition[32]; } orc_biquad_teensy; /* filter_biquad.h:152 */
+void orc_biquad_teensy_init(orc_biquad_teensy *b);                       /* h:36-39 */
+void orc_biquad_teensy_set_coefficients(orc_biquad_teensy *b, uint32_t stage,
+                                        const int32_t coef[5]);          /* cpp:84-100 */
+void orc_biquad_teensy_update(orc_biquad_teensy *b, int16_t *data, uint32_t n); /* cpp:33-82 */
+/* cookbook designers, filter_biquad.h:56-149; sample_rate = AUDIO_SAMPLE_RATE_EXACT there */
+enum { ORC_BQ_LOWPASS = 0, ORC_BQ_HIGHPASS, ORC_BQ_BANDPASS, ORC_BQ_NOTCH,
+       ORC_BQ_LOWSHELF, ORC_BQ_HIGHSHELF };
+void orc_biquad_design(int kind, float frequency, float q_or_gain, float slope,
+                       double sample_rate, int32_t coef[5]);
+#define ORC_AUDIO_SAMPLE_RATE_EXACT 44117.64706 /* Teensy core constant (not in the repo) */
+
+/* ---- A8: arm_biquad_cascade_df1_f32 (CMSIS-DSP 1.5.x semantics; prototype arm_math.h:1333) */
+typedef struct {
+    uint32_t numStages;
+    float *pState;        /* 4*numStages: x[n-1],x[n-2],y[n-1],y[n-2] (arm_math.h:1233) */
+    const float *pCoeffs; /* 5*numStages: b0,b1,b2,a1,a2 (feedback terms ADDED) */
+} orc_biquad_df1_f32;
+void orc_biquad_df1_init_f32(orc_biquad_df1_f32 *S, uint8_t numStages, const float *pCoeffs,
+                             float *pState);
+void orc_biquad_df1_f32_run(const orc_biquad_df1_f32 *S, const float *pSrc, float *pDst,
+                            uint32_t blockSize);
+
+/* ---- A9: FIR designer, Minimal-SDR.ino:782-899 ------------------------------------------ */
+float orc_izero(float x);            /* :883-899 */
+float orc_m_sinc(int m, float fc);   /* :874-881 */
+void orc_set_pi_double(int on);      /* which `PI` the sketch saw: see msdr_oracle.c A9 */
+void orc_calc_fir_coeffs(int16_t *coeffs, int numCoeffs, float fc, float Astop, int type,
+                         float dfc, float Fsamprate);
+
+/* ---- whole-chain drivers (compositions of the above, as demodulation() composes them) ---- */
+typedef struct {
+    int mode;                 /* ORC_AM / ORC_LSB / ORC_USB / ORC_CW */
+    int sqrt_kind;            /* ORC_SQRT_F32 | ORC_SQRT_Q31 */
+    int mixer;                /* 0 = Fs/4 inline mixer (A1); 1 = freq_conv node (A2), dir=1, Q input = 0 */
+    uint32_t num_taps;
+    const q15_t *coeffs_i;    /* num_taps */
+    const q15_t *coeffs_q;
+    const q15_t *osc_i;       /* ORC_BLOCK entries, used when mixer==1 */
+    const q15_t *osc_q;
+    uint32_t n_biquad_nodes;  /* 0..2 AudioFilterBiquad nodes after the demodulator (.ino:77-81) */
+    const struct orc_biquad_teensy_s *bq_init; /* batch drivers: initial node records (coefficients) */
+} orc_chain_q15_cfg;
+typedef struct {
+    q15_t *state_i;           /* num_taps + ORC_BLOCK */
+    q15_t *state_q;
+    orc_biquad_teensy bq[2];
+} orc_chain_q15_state;
+/* Processes n_blocks consecutive blocks of ORC_BLOCK samples of ONE channel.
+ * i_out/q_out (may be NULL) receive the post-FIR I/Q intermediates. */
+void orc_chain_q15(const orc_chain_q15_cfg *cfg, orc_chain_q15_state *st, const int16_t *x,
+                   int16_t *audio, int16_t *i_out, int16_t *q_out, uint32_t n_blocks);
+
+typedef struct {
+    int mode;                 /* ORC_AM / ORC_LSB / ORC_USB / ORC_CW */
+    float in_scale;           /* int16 -> float scale (1/32768 = arm_q15_to_float convention) */
+    uint32_t num_taps;
+    const float *coeffs_i;
+    const float *coeffs_q;
+    uint32_t osc_len;         /* NCO table period (freq_conv: one block) */
+    const float *osc_i;       /* "sin" table */
+    const float *osc_q;       /* "cos" table */
+    uint32_t num_stages;      /* 0..4 */
+    const float *bq_coeffs;   /* 5*num_stages */
+} orc_chain_f32_cfg;
+typedef struct {
+    float *hist_i;            /* num_taps-1 history */
+    float *hist_q;
+    float bq_state[16];
+    uint64_t n0;              /* absolute sample index of the next input sample (NCO phase) */
+} orc_chain_f32_state;
+/* One channel, n samples, sample-sequential, sequential tap order, no FMA contraction. */
+void orc_chain_f32(const orc_chain_f32_cfg *cfg, orc_chain_f32_state *st, const int16_t *x,
+                   float *audio, uint64_t n);
+
+/* batched CPU-baseline drivers: channel c uses x + c*n, audio + c*n; fresh zero state per call.
+ * Channels are spread over `threads` OpenMP threads (schedule(static)). Returns threads used. */
+int orc_chain_f32_batch(const orc_chain_f32_cfg *cfg, const int32_t *mode_per_channel,
+                        const int16_t *x, float *audio, uint32_t channels, uint64_t n,
+                        int threads);
+int orc_chain_q15_batch(const orc_chain_q15_cfg *cfg, const int32_t *mode_per_channel,
+                        const int16_t *x, int16_t *audio, uint32_t channels,
+                        uint32_t n_blocks, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,146 @@
+"""Pin the CPU oracle (oracle/msdr_oracle.c) against the reference.
+
+Two anchors:
+  * `ref`    -- oracle/_ref/libmsdr_ref.so, the reference's own sources compiled in this container
+               (skipped where /root/reference is absent, e.g. on the GPU box if not prebuilt);
+  * `golden` -- tests/golden/golden.npz, outputs of that compiled reference, committed.
+Bit-exact everywhere (integer path)."""
+import numpy as np
+import pytest
+
+import goldenlib
+import orclib
+
+B = orclib.BLOCK
+
+
+def test_golden_manifest_intact(golden):
+    assert goldenlib.verify(golden) == []
+
+
+# ---------------------------------------------------------------- A9 designer -------------
+def test_designer_matches_golden(orc, golden):
+    for (n, fc, a, t, dfc) in golden.meta["design_cases"]:
+        for pid in (False, True):
+            want = golden["design/n%d_fc%d_a%d_t%d_d%d_%s" % (n, fc, a, t, dfc, "pid" if pid else "pif")]
+            got = orc.calc_fir_coeffs(n, fc, a, t, dfc, 24000.0, pi_double=pid, room=want.size)
+            assert np.array_equal(got, want), (n, fc, a, t, dfc, pid)
+
+
+def test_designer_known_answers_from_survey(orc):
+    # calc_FIR_coeffs(...,102, 2800, 70, 0, 0, 24000)
+    c = orc.calc_fir_coeffs(102, 2800)[:102].astype(int)
+    assert list(c[49:54]) == [5161, 6970, 7645, 6970, 5161]
+    assert c[0] == 0 and list(c[1:4]) == [-2, -3, -2]
+    assert c.sum() == 32761 and np.abs(c).sum() == 59529
+
+
+def test_designer_matches_reference_live(orc, ref):
+    rng = np.random.default_rng(11)
+    for _ in range(60):
+        n = int(rng.integers(4, 300)) & ~1
+        fc = float(rng.integers(100, 9000))
+        a = float(rng.choice([10.0, 30.0, 45.5, 50.0, 70.0, 90.0]))
+        t = int(rng.integers(0, 4))
+        dfc = float(rng.integers(50, 2000))
+        for pid in (False, True):
+            want = ref.calc_fir_coeffs(n, fc, a, t, dfc, 24000.0, pi_double=pid)
+            got = orc.calc_fir_coeffs(n, fc, a, t, dfc, 24000.0, pi_double=pid)
+            assert np.array_equal(got, want), (n, fc, a, t, dfc, pid)
+    for n in (8, 32, 64):  # Hilbert branch (type 4), never used by the app
+        assert np.array_equal(orc.calc_fir_coeffs(n, 0, 70, 4), ref.calc_fir_coeffs(n, 0, 70, 4))
+
+
+def test_izero_msinc_match_reference_live(orc, ref):
+    for x in np.linspace(0, 12, 97, dtype=np.float32):
+        assert orc.lib.orc_izero(float(x)) == ref.lib.Izero(float(x))
+    for m in range(-40, 41, 2):
+        for fc in (0.01, 0.2333, 0.5):
+            assert orc.lib.orc_m_sinc(m, fc) == ref.lib.m_sinc(m, fc)
+
+
+# ---------------------------------------------------------------- A3/A4 q15 FIR -----------
+FIR_TAPS = ["ssb_i", "ssb_q", "am102", "lp256", "lp512", "lp62", "wrap8", "n4", "n6"]
+
+
+@pytest.mark.parametrize("tn", FIR_TAPS)
+def test_fir_q15_matches_golden(orc, golden, tn):
+    taps = golden["fir/taps_" + tn]
+    for sn in ("noise", "full"):
+        x = golden["fir/x_" + sn]
+        for blk in (128, 130, 7):
+            rc, y = orc.fir_q15_blocks(taps, x, blk)
+            assert rc == 0
+            assert np.array_equal(y, golden["fir/%s_%s_b%d" % (tn, sn, blk)]), (tn, sn, blk)
+
+
+def test_fir_q15_accumulator_wraps_not_saturates(golden):
+    # 8 taps of 32767 on full-scale input overflow 2^31: the golden (reference) output must differ
+    # from a saturating/64-bit model, i.e. the fixture really exercises the wrap.
+    x = golden["fir/x_full"].astype(np.int64)
+    w = np.concatenate([np.zeros(7, np.int64), x])
+    acc = np.array([(w[n:n + 8] * 32767).sum() for n in range(x.size)])
+    wide = np.clip(acc >> 15, -32768, 32767)
+    assert (wide != golden["fir/wrap8_full_b128"]).any()
+    wrapped = ((acc + 2 ** 31) % 2 ** 32 - 2 ** 31) >> 15
+    assert np.array_equal(np.clip(wrapped, -32768, 32767), golden["fir/wrap8_full_b128"])
+
+
+def test_fir_q15_init_rejects_odd_taps(orc, golden):
+    assert golden.meta["fir_init_odd_taps_status"] == -1      # ARM_MATH_ARGUMENT_ERROR
+    rc, _ = orc.fir_q15_blocks(np.ones(5, np.int16), np.zeros(B, np.int16), B)
+    assert rc == -1
+
+
+def test_fir_q15_matches_reference_live(orc, ref):
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        n = int(rng.integers(2, 140)) * 2
+        amp = int(rng.choice([300, 8000, 32767]))
+        taps = rng.integers(-amp, amp + 1, n).astype(np.int16)
+        blk = int(rng.choice([1, 2, 3, 4, 5, 64, 127, 128, 129, 256]))
+        x = rng.integers(-32768, 32768, blk * int(rng.integers(1, 5))).astype(np.int16)
+        rc_o, y_o = orc.fir_q15_blocks(taps, x, blk)
+        rc_r, y_r = ref.fir_q15_blocks(taps, x, blk)
+        assert rc_o == rc_r == 0
+        assert np.array_equal(y_o, y_r), (n, amp, blk)
+
+
+def test_copy_and_sqrt_q31(orc, golden):
+    assert np.array_equal(golden["copy_q15/out"], golden["chain/x_full"][:131])
+    for v, want in zip(golden["sqrt_q31/in"], golden["sqrt_q31/out"]):
+        assert orc.sqrt_q31(int(v))[1] == int(want), int(v)
+
+
+def test_sqrt_q31_matches_reference_live(orc, ref):
+    rng = np.random.default_rng(9)
+    vals = list(rng.integers(-5, 2 ** 31, 3000)) + [2 ** 31 - 1, 1, 0, -2 ** 31] + [2 ** k for k in range(31)]
+    for v in vals:
+        assert orc.sqrt_q31(int(v)) == ref.sqrt_q31(int(v)), int(v)
+
+
+# ---------------------------------------------------------------- A1+A4+A5 chain ----------
+CHAIN = [("AM", orclib.AM, "fir/taps_am102", "fir/taps_am102"),
+         ("LSB", orclib.LSB, "taps/FIR_SSB_I_coeffs", "taps/FIR_SSB_Q_coeffs"),
+         ("USB", orclib.USB, "taps/FIR_SSB_I_coeffs", "taps/FIR_SSB_Q_coeffs"),
+         ("CW", orclib.CW, "taps/FIR_CW_I_coeffs", "taps/FIR_CW_Q_coeffs")]
+
+
+@pytest.mark.parametrize("sn", ["am", "tones", "noise", "full"])
+@pytest.mark.parametrize("mn,mode,ti,tq", CHAIN)
+def test_chain_q15_matches_golden(orc, golden, sn, mn, mode, ti, tq):
+    x = golden["chain/x_" + sn]
+    audio, i, q = orc.chain_q15(x, mode, golden[ti], golden[tq], want_iq=True)
+    assert np.array_equal(i, golden["chain/%s_%s_I" % (sn, mn)])
+    assert np.array_equal(q, golden["chain/%s_%s_Q" % (sn, mn)])
+    assert np.array_equal(audio, golden["chain/%s_%s_audio" % (sn, mn)])
+    if mn in ("AM", "CW"):
+        a2 = orc.chain_q15(x, mode, golden[ti], golden[tq], sqrt_kind=orclib.SQRT_Q31)
+        assert np.array_equal(a2, golden["chain/%s_%s_audio_q31" % (sn, mn)])
+
+
+def test_static_tables_properties(golden):
+    # Q = reverse(I) for both static pairs; sum|c| as probed
+    for a, b, s in (("FIR_SSB_I_coeffs", "FIR_SSB_Q_coeffs", 59369), ("FIR_CW_I_coeffs", "FIR_CW_Q_coeffs", 42358)):
+        assert np.array_equal(golden["taps/" + a], golden["taps/" + b][::-1])
+        assert np.abs(golden["taps/" + a].astype(int)).sum() == s

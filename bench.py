@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the fused demodulation chain on MI355X (one JSON line on rank 0).
+
+A "step" is ONE pass of the hot path (IF -> I/Q mix -> FIR pair -> demod -> IIR cascade) over one
+block batch of synthetic IF that is already resident in HBM.  Workloads (BASELINE.json configs):
+  c2 (default)  1 SSB channel, freq_conv-style NCO tables, 100-tap Hilbert pair, LSB (I-Q), 2-stage biquad,
+                2^30 int16 IF samples per step, fp32 audio out                       [configs[1]]
+  c3            4096 AM channels x 2^18 samples, 256-tap fp32 low-pass pair, Fs/4 mixer  [configs[2]]
+  c4            8192 SSB channels per GPU x 2^14 samples, 100-tap pair, LSB              [configs[3]]
+  c5            mixed AM/LSB per channel, 512 taps, 1 Mi-sample blocks, 256 channels/GPU [configs[4]]
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  Channels are independent,
+so every rank runs its own shard with NO data-path collective ("weak" scaling); the RCCL gather of
+demodulated audio is timed separately, outside the timed region, and reported under "gather".
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "minimal-sdr_amd", "python"))
+
+FS = 24000.0
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
+
+
+def hilbert_pair(n_taps, fc=1330.0, bw=1920.0):
+    k = np.arange(n_taps)
+    m = (n_taps - 1) / 2.0
+    proto = np.sinc(bw / FS * (k - m)) * np.kaiser(n_taps, 6.0)
+    proto /= proto.sum()
+    w = 2 * np.pi * fc / FS
+    return ((2 * proto * np.cos(w * (k - m) + np.pi / 4)).astype(np.float32),
+            (2 * proto * np.cos(w * (k - m) - np.pi / 4)).astype(np.float32))
+
+
+def lowpass(n_taps, fc=2800.0):
+    k = np.arange(n_taps)
+    h = np.sinc(2 * fc / FS * (k - (n_taps - 1) / 2.0)) * np.kaiser(n_taps, 7.0)
+    return (h / h.sum()).astype(np.float32)
+
+
+def reference_biquads(msdr):
+    """biquad1_dac: LP 0.9*6 kHz Q=0.54 (.ino:391-393); biquad2_dac: notch fs/8 Q=15 (.ino:356); CMSIS sign."""
+    corr = msdr.AUDIO_SAMPLE_RATE_EXACT / FS
+    out = []
+    for kind, f, q in ((msdr.BQ_LOWPASS, 6000 * 0.9 * corr, 0.54), (msdr.BQ_NOTCH, FS / 8 * corr, 15.0)):
+        c = msdr.biquad_design(kind, np.float32(f), q).astype(np.float64) / 2 ** 30
+        out.append([c[0], c[1], c[2], -c[3], -c[4]])
+    return np.array(out, np.float32)
+
+
+def workload(name, msdr, rank):
+    osc_n = np.arange(128)
+    osc_i = np.sin(2 * np.pi * 32 * osc_n / 128).astype(np.float32)      # Osc_I_buffer_i ("sin"), fs/4
+    osc_q = np.cos(2 * np.pi * 32 * osc_n / 128).astype(np.float32)
+    bq = reference_biquads(msdr)
+    if name == "c2":
+        hi, hq = hilbert_pair(100)
+        return dict(name="c2: 1 SSB channel, NCO mix + 100-tap Hilbert pair + LSB + 2-stage biquad, 2^30 int16 IF",
+                    channels=1, n=1 << 30, taps=100, ci=[hi], cq=[hq], mixer=msdr.MIXER_NCO, osc=(osc_i, osc_q),
+                    modes=None, tapsets=None, mode=msdr.MODE_LSB, bq=bq, seed=2 + 1000 * rank)
+    if name == "c3":
+        lp = lowpass(256)
+        return dict(name="c3: 4096 AM channels x 2^18, Fs/4 mix + 256-tap low-pass pair + envelope + 2-stage biquad",
+                    channels=4096, n=1 << 18, taps=256, ci=[lp], cq=[lp], mixer=msdr.MIXER_FS4, osc=None,
+                    modes=None, tapsets=None, mode=msdr.MODE_AM, bq=bq, seed=3 + 1000 * rank)
+    if name == "c4":
+        hi, hq = hilbert_pair(100)
+        return dict(name="c4: 8192 SSB channels/GPU x 2^14, NCO mix + 100-tap Hilbert pair + LSB + 2-stage biquad",
+                    channels=8192, n=1 << 14, taps=100, ci=[hi], cq=[hq], mixer=msdr.MIXER_NCO, osc=(osc_i, osc_q),
+                    modes=None, tapsets=None, mode=msdr.MODE_LSB, bq=bq, seed=4 + 1000 * rank)
+    if name == "c5":
+        ch = 256
+        lp = lowpass(512)
+        hi, hq = hilbert_pair(512)
+        modes = np.array([msdr.MODE_AM if ((c + ch * rank) * 2654435761 >> 7) & 1 else msdr.MODE_LSB for c in range(ch)], np.int32)
+        tapsets = np.array([0 if m == msdr.MODE_AM else 1 for m in modes], np.int32)
+        return dict(name="c5: 256 mixed AM/LSB channels/GPU x 2^20, Fs/4 mix + 512-tap pair + 2-stage biquad",
+                    channels=ch, n=1 << 20, taps=512, ci=[lp, hi], cq=[lp, hq], mixer=msdr.MIXER_FS4, osc=None,
+                    modes=modes, tapsets=tapsets, mode=msdr.MODE_AM, bq=bq, seed=5 + 1000 * rank)
+    raise SystemExit("unknown workload " + name)
+
+
+def synth_if(torch, dev, channels, n, seed):
+    """Two tones (6.7 kHz, 5.4 kHz at -6 dB) + uniform noise +-500, int16, generated on the device."""
+    x = torch.empty((channels, n), dtype=torch.int16, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    flat = x.view(-1)
+    total = channels * n
+    step = 1 << 24
+    for o in range(0, total, step):
+        m = min(step, total - o)
+        t = ((torch.arange(o, o + m, device=dev, dtype=torch.int64) % n) % 240000).to(torch.float32)   # both tones have a 240000-sample period
+        v = 6000.0 * torch.cos(t * (2 * math.pi * 6700.0 / FS)) + 3000.0 * torch.cos(t * (2 * math.pi * 5400.0 / FS) + 0.3)
+        v += torch.randint(-500, 501, (m,), device=dev, generator=g).to(torch.float32)
+        flat[o:o + m] = v.round().to(torch.int16)
+    return x
+
+
+def cpu_baseline(wl, x_host, gpu_first, target_s=12.0):
+    """Time the oracle (CPU restatement, "port") on a bounded sample of the SAME input: the first
+    samples of up to `threads` channels; one-channel workloads are cut into per-thread time chunks
+    (fresh zero state per chunk: identical arithmetic work per sample).  Also returns parity of the
+    GPU output against the oracle on that sample (first chunk of each channel only)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orclib
+    orc = orclib.Oracle()
+    threads = os.cpu_count() or 1
+    osc_i, osc_q = wl["osc"] if wl["osc"] else (np.array([0, 1, 0, -1], np.float32), np.array([1, 0, -1, 0], np.float32))
+    modes_all = wl["modes"] if wl["modes"] is not None else np.full(wl["channels"], wl["mode"], np.int32)
+    tapsets_all = wl["tapsets"] if wl["tapsets"] is not None else np.zeros(wl["channels"], np.int32)
+
+    def run(xs, modes, ts, thr):
+        # one tap set per oracle call: group rows by tap set
+        t0 = time.perf_counter()
+        outs = np.empty(xs.shape, np.float32)
+        used = 1
+        for s in sorted(set(ts.tolist())):
+            idx = np.nonzero(ts == s)[0]
+            o, used = orc.chain_f32_batch(xs[idx], modes[idx], wl["ci"][s], wl["cq"][s], osc_i, osc_q, wl["bq"], threads=thr)
+            outs[idx] = o
+        return outs, time.perf_counter() - t0, used
+
+    # 1-thread rate on a short prefix
+    cal_n = min(x_host.shape[1], 200000)
+    _, dt1, _ = run(x_host[:1, :cal_n], modes_all[:1], tapsets_all[:1], 1)
+    rate1 = cal_n / dt1
+    if x_host.shape[0] == 1:                                  # one channel: cut the sample into per-thread time chunks
+        chunks = max(1, min(threads, x_host.shape[1] // 65536))
+        per_row = x_host.shape[1] // chunks
+        xs = np.ascontiguousarray(x_host[0, :chunks * per_row].reshape(chunks, per_row))
+        modes, ts = np.full(chunks, modes_all[0], np.int32), np.full(chunks, tapsets_all[0], np.int32)
+    else:
+        per_row = x_host.shape[1]
+        xs, modes, ts = x_host, modes_all[:x_host.shape[0]], tapsets_all[:x_host.shape[0]]
+    total_dt, passes, outs, used = 0.0, 0, None, 1
+    while total_dt < target_s and passes < 50:                # repeat whole passes until ~target_s of wall time
+        outs, dt, used = run(xs, modes, ts, threads)
+        total_dt += dt
+        passes += 1
+    rate = xs.size * passes / total_dt
+    # parity on rows that start at stream position 0 with zero state
+    par_rows = [0] if x_host.shape[0] == 1 else list(range(xs.shape[0]))
+    worst = 0.0
+    for r in par_rows:
+        m = min(per_row, gpu_first.shape[1])
+        want, got = outs[r, :m].astype(np.float64), gpu_first[r, :m].astype(np.float64)
+        worst = max(worst, float(np.sqrt(((got - want) ** 2).sum() / max((want ** 2).sum(), 1e-300))))
+    return {"value": round(rate / 1e6, 3), "unit": "Msamples/s", "cores": int(min(used, xs.shape[0])), "kind": "port",
+            "sample": "%d row(s) x %d samples of the same IF input, %d pass(es), %.1f s wall (oracle/msdr_oracle.c orc_chain_f32; "
+                      "1-thread rate %.2f Msamples/s)" % (xs.shape[0], per_row, passes, total_dt, rate1 / 1e6)}, worst, min(per_row, gpu_first.shape[1])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--samples", type=int, default=0, help="override samples per channel per step")
+    ap.add_argument("--channels", type=int, default=0, help="override channels per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-fold", action="store_true", help="keep mixer and FIR as separate arithmetic steps")
+    ap.add_argument("--time-segments", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import msdr
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the library has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    wl = workload(args.workload, msdr, rank)
+    if args.samples:
+        wl["n"] = args.samples
+    if args.channels:
+        wl["channels"] = args.channels
+        if wl["modes"] is not None:
+            wl["modes"], wl["tapsets"] = np.resize(wl["modes"], args.channels), np.resize(wl["tapsets"], args.channels)
+    ch, n = wl["channels"], wl["n"]
+
+    stream = torch.cuda.current_stream(dev)
+    ctx = msdr.Context(local_rank, stream.cuda_stream)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, wl["ci"], wl["cq"], mixer=wl["mixer"], mode=wl["mode"], modes=wl["modes"],
+                       tapsets=wl["tapsets"], osc_i=wl["osc"][0] if wl["osc"] else None, osc_q=wl["osc"][1] if wl["osc"] else None,
+                       biquad_coeffs=wl["bq"], time_segments=args.time_segments,
+                       flags=msdr.CHAIN_NO_TAP_FOLDING if args.no_fold else 0)
+    x = synth_if(torch, dev, ch, n, wl["seed"])
+    y = torch.empty((ch, n), dtype=torch.float32, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # first pass from zero state: kept for the parity check against the oracle
+    chain.process(x.data_ptr(), y.data_ptr(), n)
+    torch.cuda.synchronize(dev)
+    first_rows = min(ch, os.cpu_count() or 1)
+    keep = min(n, 1 << 22)                                     # GPU audio kept for the parity check
+    keep_x = min(n, (1 << 26) if ch == 1 else (1 << 22))       # IF sample handed to the CPU baseline
+    gpu_first = y[:first_rows, :keep].cpu().numpy() if rank == 0 else None
+    for _ in range(max(0, args.warmup - 1)):
+        chain.process(x.data_ptr(), y.data_ptr(), n)
+    chain.enable_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        chain.process(x.data_ptr(), y.data_ptr(), n)
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = chain.kernel_time()
+    chain.enable_timing(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    gather = None
+    if dist is not None:                                       # RCCL gather of demodulated audio, timed on its own
+        m = min(ch * n, 1 << 24)
+        part = y.view(-1)[:m].contiguous()
+        full = torch.empty((world * m,), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(full, part)
+        barrier()
+        g0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            dist.all_gather_into_tensor(full, part)
+        barrier()
+        gdt = (time.perf_counter() - g0) / reps
+        gather = {"op": "all_gather_into_tensor (RCCL)", "bytes_per_rank": m * 4, "ms": round(gdt * 1e3, 3),
+                  "GBps_into_each_rank": round((world - 1) * m * 4 / gdt / 1e9, 1),
+                  "Msamples_per_s": round(world * m / gdt / 1e6, 1)}
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    info = chain.info()
+    samples_per_step = ch * n
+    value = world * samples_per_step * args.steps / dt / 1e6
+    k_ms = kernel_ms / max(launches, 1)
+    alg_bytes = 6.0 * samples_per_step                          # int16 in + fp32 out
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    flop_per_sample = 4.0 * wl["taps"] + (6 if wl["mixer"] == msdr.MIXER_NCO else 0) + 4 + 9 * len(wl["bq"])
+    out = {
+        "metric": "Msamples/s through IF->I/Q->FIR->demod->IIR chain; achieved HBM GB/s vs peak",
+        "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl["name"], "channels_per_gpu": ch, "samples_per_channel_per_step": n, "taps": wl["taps"],
+                   "biquad_stages": int(len(wl["bq"])), "in": "int16", "out": "fp32", "sharding": "independent channels per GPU, no data-path collective",
+                   "kernel": info["kernel"], "grid": info["grid"], "time_segments": info["time_segments"], "iir_warmup": info["warmup"],
+                   "tap_folding": not args.no_fold},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel_ms": round(k_ms, 4), "launches_timed": int(launches),
+                     "valu_tflops_as_written": round(flop_per_sample * samples_per_step / (k_ms * 1e-3) / 1e12, 2),
+                     "valu_frac_as_written": round(flop_per_sample * samples_per_step / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)},
+    }
+    if gather:
+        out["gather"] = gather
+    if not args.no_cpu and world == 1:
+        x_host = x[:first_rows, :keep_x].cpu().numpy()
+        cb, worst, per_row = cpu_baseline(wl, x_host, gpu_first)
+        out["cpu_baseline"] = cb
+        out["parity"] = {"rel_rms_worst": float("%.3g" % worst), "tolerance": 1e-5, "rows": int(min(first_rows, max(1, x_host.shape[0]))),
+                         "samples_per_row": int(per_row)}
+    elif not args.no_cpu:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

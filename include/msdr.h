@@ -1,0 +1,237 @@
+/*
+ * include/msdr.h -- C ABI of the MI355X-native Minimal-SDR demodulation chain.
+ *
+ * Drop-in boundary for the hot path of FrankBoesing/Minimal-SDR (citations relative to the
+ * reference tree): IF samples -> I/Q mix -> FIR pair -> AM/SSB demod -> cascaded IIR biquad.
+ * Plain C: pointers and sizes only; no C++/torch types.  Every function returns an msdr_status
+ * (0 = OK; negative values mirror CMSIS `arm_status`, src/CMSIS_5/arm_math.h:404-413) and never
+ * throws.  The library never takes ownership of caller buffers.
+ *
+ * Memory convention: pointers named `d_*` are DEVICE pointers (hipMalloc / msdr_malloc /
+ * torch tensor data_ptr) valid on the context's GPU; all other pointers are HOST pointers that
+ * are read during the call and not retained (the reference's CMSIS functions retain the caller's
+ * coefficient/state pointers, arm_fir_init_q15.c:100-109 -- here the library copies coefficients
+ * to the device and owns the state, which lives in HBM between calls).
+ *
+ * Batch layout in HBM: a "block batch" is [channels][block_len] row-major, one contiguous time
+ * series per receiver channel (the reference's unit is one audio_block_t = int16[128] of ONE
+ * channel, freq_conv.cpp:70, filter_biquad.cpp:42).  Channels are independent.
+ *
+ * All work is enqueued on the context's HIP stream and is asynchronous with respect to the
+ * host; msdr_ctx_synchronize() (or synchronising the stream you supplied) waits for it.
+ * There is NO CPU fallback: if no HIP device is usable every entry point fails with
+ * MSDR_STATUS_NO_DEVICE.
+ */
+#ifndef MSDR_H
+#define MSDR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSDR_VERSION_MAJOR 0
+#define MSDR_VERSION_MINOR 1
+
+typedef int16_t q15_t;     /* arm_math.h:423 */
+typedef float float32_t;   /* arm_math.h:438 */
+
+/* ---- status: arm_status values (arm_math.h:404-413) + device errors ------------------- */
+typedef enum {
+    MSDR_STATUS_SUCCESS        = 0,   /* ARM_MATH_SUCCESS */
+    MSDR_STATUS_ARGUMENT_ERROR = -1,  /* ARM_MATH_ARGUMENT_ERROR (e.g. odd numTaps, arm_fir_init_q15.c:93-96) */
+    MSDR_STATUS_LENGTH_ERROR   = -2,  /* ARM_MATH_LENGTH_ERROR */
+    MSDR_STATUS_SIZE_MISMATCH  = -3,  /* ARM_MATH_SIZE_MISMATCH */
+    MSDR_STATUS_NO_DEVICE      = -100,/* no usable HIP device / wrong architecture */
+    MSDR_STATUS_HIP_ERROR      = -101,/* a HIP runtime call failed: see msdr_last_error() */
+    MSDR_STATUS_OUT_OF_MEMORY  = -102
+} msdr_status;
+
+/* ---- demodulator modes: stations.h:4  enum { SYNCAM, AM, LSB, USB, CW } ---------------- */
+enum { MSDR_MODE_SYNCAM = 0, MSDR_MODE_AM = 1, MSDR_MODE_LSB = 2, MSDR_MODE_USB = 3, MSDR_MODE_CW = 4 };
+/* AM/CW magnitude: Minimal-SDR.ino:606-616 (Teensy 3.6: sqrtf) or :618-627 (Teensy 3.2: arm_sqrt_q31>>16) */
+enum { MSDR_SQRT_F32 = 0, MSDR_SQRT_Q31 = 1 };
+/* mixer in front of the FIR pair */
+enum {
+    MSDR_MIXER_FS4 = 0,   /* multiplication-free Fs/4 mixer, Minimal-SDR.ino:546-558 */
+    MSDR_MIXER_NCO = 1    /* AudioEffectFreqConv, freq_conv.cpp:30-116: IF on port 0, zeros on port 1, dir = 1 */
+};
+/* arithmetic flavour of a chain */
+enum {
+    MSDR_ARITH_Q15 = 0,   /* the reference as written: arm_fir_fast_q15 + integer demod + Teensy biquad; bit-exact */
+    MSDR_ARITH_F32 = 1    /* arm_fir_f32 / arm_biquad_cascade_df1_f32 semantics, int16 in, fp32 out */
+};
+#define MSDR_AUDIO_BLOCK_SAMPLES 128           /* Teensy core default (Minimal-SDR.ino:525) */
+#define MSDR_AUDIO_SAMPLE_RATE_EXACT 44117.64706 /* Teensy core constant used by filter_biquad.h:58 */
+#define MSDR_MAX_BIQUAD_STAGES 4               /* filter_biquad.cpp:86 */
+#define MSDR_MAX_TAPSETS 8
+
+/* ======================================================================================
+ * Context: one GPU + one HIP stream.
+ * ====================================================================================== */
+typedef struct msdr_ctx msdr_ctx;
+
+/* device: HIP device ordinal.  hip_stream: a hipStream_t to enqueue on (e.g. torch's current
+ * stream), or NULL to let the context create and own one. */
+int  msdr_ctx_create(int device, void *hip_stream, msdr_ctx **out);
+int  msdr_ctx_destroy(msdr_ctx *ctx);
+int  msdr_ctx_synchronize(msdr_ctx *ctx);
+void *msdr_ctx_stream(msdr_ctx *ctx);                       /* the hipStream_t in use */
+const char *msdr_last_error(void);                          /* thread-local text of the last failure */
+const char *msdr_version(void);
+int  msdr_device_count(void);                               /* usable gfx950 devices; never initialises one */
+
+/* device-memory helpers (callers may equally pass pointers from hipMalloc or a torch tensor) */
+int msdr_malloc(msdr_ctx *ctx, size_t bytes, void **d_ptr);
+int msdr_free(msdr_ctx *ctx, void *d_ptr);
+int msdr_memcpy_h2d(msdr_ctx *ctx, void *d_dst, const void *src, size_t bytes);   /* stream-ordered, returns after the copy */
+int msdr_memcpy_d2h(msdr_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+int msdr_memset(msdr_ctx *ctx, void *d_dst, int value, size_t bytes);
+
+/* ======================================================================================
+ * Host-side designers (setup path; pure CPU arithmetic, no device needed).
+ * ====================================================================================== */
+/* calc_FIR_coeffs, Minimal-SDR.ino:782-872 (with m_sinc :874-881, Izero :883-899).  Same
+ * argument list and same overrun behaviour as the reference: type 0 writes numCoeffs entries,
+ * types 2/3 write numCoeffs+1, type 4 (Hilbert) writes up to 2*numCoeffs+2. */
+void msdr_calc_FIR_coeffs(int16_t *coeffs, int numCoeffs, float32_t fc, float32_t Astop, int type,
+                          float dfc, float Fsamprate);
+/* AudioFilterBiquad::setLowpass/.../setHighShelf, src/Audio/filter_biquad.h:56-149.
+ * coef[5] = {b0,b1,b2,a1,a2} scaled by 2^30 in textbook sign, exactly what the reference hands
+ * to setCoefficients(stage, const int*).  sample_rate: the reference hard-codes
+ * AUDIO_SAMPLE_RATE_EXACT (callers multiply cut-offs by CORR_FACT, Minimal-SDR.ino:86,391). */
+enum { MSDR_BQ_LOWPASS = 0, MSDR_BQ_HIGHPASS, MSDR_BQ_BANDPASS, MSDR_BQ_NOTCH, MSDR_BQ_LOWSHELF, MSDR_BQ_HIGHSHELF };
+int msdr_biquad_design(int kind, float frequency, float q_or_gain, float slope, double sample_rate, int32_t coef[5]);
+
+/* ======================================================================================
+ * Kernel-function API: CMSIS-DSP / Teensy-Audio mirrors, batched over channels.
+ * Instances are opaque handles (state lives in HBM); `blockSize` may differ between calls.
+ * d_src/d_dst: [channels][blockSize].  In-place (d_dst == d_src) is allowed where the
+ * reference allows it.
+ * ====================================================================================== */
+
+/* arm_fir_init_q15 / arm_fir_fast_q15 (arm_math.h:1106-1128; arm_fir_init_q15.c:78-138,
+ * arm_fir_fast_q15.c:60-329).  pCoeffs: host, numTaps entries in CMSIS (time-reversed) order,
+ * shared by all channels.  Odd numTaps -> MSDR_STATUS_ARGUMENT_ERROR like the reference.
+ * Creation zeroes the state (arm_fir_init_q15.c:106). */
+typedef struct msdr_fir_q15 msdr_fir_q15;
+int msdr_fir_q15_create(msdr_ctx *ctx, uint16_t numTaps, const q15_t *pCoeffs, uint32_t channels, msdr_fir_q15 **out);
+int msdr_fir_q15_process(msdr_fir_q15 *S, const q15_t *d_src, q15_t *d_dst, uint32_t blockSize);
+int msdr_fir_q15_reset(msdr_fir_q15 *S);
+int msdr_fir_q15_destroy(msdr_fir_q15 *S);
+
+/* arm_fir_init_f32 / arm_fir_f32 (prototypes arm_math.h:1182-1202; CMSIS-DSP V1.5.x). Any numTaps >= 1. */
+typedef struct msdr_fir_f32 msdr_fir_f32;
+int msdr_fir_f32_create(msdr_ctx *ctx, uint16_t numTaps, const float32_t *pCoeffs, uint32_t channels, msdr_fir_f32 **out);
+int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, float32_t *d_dst, uint32_t blockSize);
+int msdr_fir_f32_reset(msdr_fir_f32 *S);
+int msdr_fir_f32_destroy(msdr_fir_f32 *S);
+
+/* arm_biquad_cascade_df1_init_f32 / arm_biquad_cascade_df1_f32 (prototypes arm_math.h:1333-1351).
+ * pCoeffs: host, 5*numStages {b0,b1,b2,a1,a2}, feedback terms ADDED (CMSIS convention). */
+typedef struct msdr_biquad_df1_f32 msdr_biquad_df1_f32;
+int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, const float32_t *pCoeffs, uint32_t channels, msdr_biquad_df1_f32 **out);
+int msdr_biquad_df1_f32_process(msdr_biquad_df1_f32 *S, const float32_t *d_src, float32_t *d_dst, uint32_t blockSize);
+int msdr_biquad_df1_f32_reset(msdr_biquad_df1_f32 *S);
+int msdr_biquad_df1_f32_destroy(msdr_biquad_df1_f32 *S);
+
+/* AudioFilterBiquad (src/Audio/filter_biquad.cpp:33-100, filter_biquad.h:33-155): up to 4 stages,
+ * Q2.30 coefficients, int16 data, 14-bit error feedback.  A new node passes nothing (all-zero
+ * definition, filter_biquad.h:36-39).  set_coefficients keeps the filter history like the
+ * reference (filter_biquad.cpp:95-97) and silently ignores stage >= 4 (:86).
+ * update(): in place on d_data [channels][blockSize]; blockSize must be even (the reference
+ * processes sample pairs, :54-74). */
+typedef struct msdr_biquad_q15 msdr_biquad_q15;
+int msdr_biquad_q15_create(msdr_ctx *ctx, uint32_t channels, msdr_biquad_q15 **out);
+int msdr_biquad_q15_set_coefficients(msdr_biquad_q15 *S, uint32_t stage, const int32_t coef[5]);
+int msdr_biquad_q15_update(msdr_biquad_q15 *S, q15_t *d_data, uint32_t blockSize);
+int msdr_biquad_q15_get_definition(msdr_biquad_q15 *S, uint32_t channel, int32_t definition[32]); /* filter_biquad.h:152 */
+int msdr_biquad_q15_destroy(msdr_biquad_q15 *S);
+
+/* Stateless per-block stages. */
+/* Minimal-SDR.ino:546-558; block must start at a sample index = 0 (mod 4), as every 128-block does */
+int msdr_mix_fs4_q15(msdr_ctx *ctx, const q15_t *d_x, q15_t *d_i, q15_t *d_q, uint32_t channels, uint32_t blockSize);
+/* AudioEffectFreqConv::update, freq_conv.cpp:30-116, in place on d_i/d_q.  osc_i/osc_q: host tables of
+ * osc_len entries (Osc_I_buffer_i / Osc_Q_buffer_i, freq_conv.h:33-34), applied at index (n mod osc_len).
+ * `pass` keeps the reference's inverted meaning: pass == 0 forwards untouched (:49-56). */
+int msdr_freqconv_q15(msdr_ctx *ctx, q15_t *d_i, q15_t *d_q, const q15_t *osc_i, const q15_t *osc_q, uint32_t osc_len,
+                      int dir, int pass, uint32_t channels, uint32_t blockSize);
+int msdr_freqconv_f32(msdr_ctx *ctx, float32_t *d_i, float32_t *d_q, const float32_t *osc_i, const float32_t *osc_q,
+                      uint32_t osc_len, int dir, int pass, uint32_t channels, uint32_t blockSize);
+/* demod switch, Minimal-SDR.ino:589-627.  d_mode: device int32 [channels] or NULL (then `mode` for all). */
+int msdr_demod_q15(msdr_ctx *ctx, int mode, const int32_t *d_mode, int sqrt_kind, const q15_t *d_i, const q15_t *d_q,
+                   q15_t *d_out, uint32_t channels, uint32_t blockSize);
+int msdr_demod_f32(msdr_ctx *ctx, int mode, const int32_t *d_mode, const float32_t *d_i, const float32_t *d_q,
+                   float32_t *d_out, uint32_t channels, uint32_t blockSize);
+
+/* ======================================================================================
+ * Fused chain = demodulation() (Minimal-SDR.ino:518-775: mix :546-558, FIR pair :574-575,
+ * demod :589-691) + the biquad nodes wired behind queue_dac (.ino:77-81), ONE kernel pass:
+ * one HBM read of the IF block batch, one HBM write of the audio block batch.
+ * ====================================================================================== */
+typedef struct {
+    uint32_t struct_size;            /* = sizeof(msdr_chain_config) */
+    int32_t  arith;                  /* MSDR_ARITH_Q15 | MSDR_ARITH_F32 */
+    uint32_t channels;
+    int32_t  mixer;                  /* MSDR_MIXER_FS4 | MSDR_MIXER_NCO */
+    /* tap sets: the reference binds one coefficient pair per mode (init_FIR, .ino:901-930) */
+    uint32_t num_taps;               /* taps per filter; q15 needs it even */
+    uint32_t num_tapsets;            /* 1..MSDR_MAX_TAPSETS */
+    const void *coeffs_i[MSDR_MAX_TAPSETS];   /* host; q15_t[num_taps] or float32_t[num_taps] by arith */
+    const void *coeffs_q[MSDR_MAX_TAPSETS];
+    /* per-channel selection (host arrays of `channels` entries, or NULL for the defaults) */
+    int32_t  default_mode;           /* MSDR_MODE_AM / LSB / USB / CW */
+    const int32_t *mode;             /* demod mode per channel */
+    const int32_t *tapset;           /* tap-set index per channel (default 0) */
+    int32_t  sqrt_kind;              /* MSDR_SQRT_F32 | MSDR_SQRT_Q31 (q15 arithmetic only) */
+    /* NCO tables for MSDR_MIXER_NCO: q15_t or float32_t by arith; index (n mod osc_len), n counted from reset */
+    uint32_t osc_len;
+    const void *osc_i;               /* "sin", Osc_I_buffer_i */
+    const void *osc_q;               /* "cos", Osc_Q_buffer_i */
+    /* IIR stage */
+    float    in_scale;               /* F32: int16 -> float scale; 0 means 1/32768 (arm_q15_to_float) */
+    uint32_t num_biquad_stages;      /* F32: 0..4 stages of arm_biquad_cascade_df1_f32 */
+    const float32_t *biquad_coeffs;  /* F32: host, 5*num_biquad_stages */
+    uint32_t num_biquad_nodes;       /* Q15: 0..2 AudioFilterBiquad nodes in series (biquad1_dac, biquad2_dac) */
+    uint32_t node_stages[2];         /* Q15: stages used in each node (1..4) */
+    const int32_t *node_coefs[2];    /* Q15: host, 5*node_stages[k] ints as given to setCoefficients */
+    /* time segmentation of one call (F32 only; see DESIGN.md "IIR along time"):
+     * 0 = automatic; 1 = never split a channel's block in time (IIR state carried exactly);
+     * k > 1 = split every channel's block into k segments, each re-converging the IIR over
+     * `biquad_warmup` samples (0 = derive from the pole radii for < 1e-9 residual). */
+    uint32_t time_segments;
+    uint32_t biquad_warmup;
+    uint32_t flags;                  /* MSDR_CHAIN_* */
+} msdr_chain_config;
+#define MSDR_CHAIN_NO_TAP_FOLDING 1u /* F32: keep mixer and FIR pair as separate arithmetic steps (as written) */
+
+typedef struct msdr_chain msdr_chain;
+int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_chain **out);
+/* d_if: int16 [channels][n_samples]; d_audio: int16 (Q15) or float (F32) [channels][n_samples].
+ * State (FIR history, IIR state, NCO phase) is carried from call to call, so calling with
+ * n_samples = 128 reproduces the reference's block cadence and one call with a long block is the
+ * same stream.  Q15 arithmetic needs n_samples even when biquad nodes are present. */
+int msdr_chain_process(msdr_chain *chain, const int16_t *d_if, void *d_audio, uint64_t n_samples);
+int msdr_chain_reset(msdr_chain *chain);                     /* init_FIR(): zero FIR + IIR state, phase 0 */
+int msdr_chain_set_mode(msdr_chain *chain, uint32_t channel, int32_t mode, int32_t tapset);
+int msdr_chain_destroy(msdr_chain *chain);
+/* introspection for benchmarks/tests: name of the main kernel variant and launch geometry of the last call */
+typedef struct {
+    char     kernel[64];
+    uint32_t grid, block, lds_bytes;
+    uint32_t time_segments, warmup, tile;
+    uint32_t taps_padded;
+} msdr_chain_info;
+int msdr_chain_get_info(msdr_chain *chain, msdr_chain_info *info);
+/* Measurement aid (bench.py): when enabled every msdr_chain_process() brackets its MAIN kernel with
+ * HIP events on the context's stream; get_kernel_time synchronises and returns the accumulated
+ * device time in ms and the number of launches timed (reset != 0 clears the accumulators). */
+int msdr_chain_enable_timing(msdr_chain *chain, int on);
+int msdr_chain_get_kernel_time(msdr_chain *chain, double *total_ms, uint64_t *launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSDR_H */

@@ -1,0 +1,839 @@
+// msdr_api.hip -- C ABI (include/msdr.h) over the gfx950 kernels in msdr_kernels.hiph.
+// Host logic only: argument checks mirroring the reference's error behaviour, coefficient/table
+// preparation, state ownership in HBM, launch geometry.  No CPU compute path exists here: every
+// process/update entry point launches HIP kernels or fails.
+#include "../../include/msdr.h"
+#include "msdr_kernels.hiph"
+#include "msdr_design.h"
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace msdr;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? MSDR_STATUS_OUT_OF_MEMORY : MSDR_STATUS_HIP_ERROR, \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *msdr_last_error(void) { return g_err.c_str(); }
+extern "C" const char *msdr_version(void) { return "msdr 0.1 (gfx950, hip)"; }
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct msdr_ctx {
+    int device;
+    hipStream_t stream;
+    bool owns_stream;
+};
+
+static int bind(msdr_ctx *ctx)
+{
+    if (!ctx) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return 0;
+}
+
+extern "C" int msdr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+extern "C" int msdr_ctx_create(int device, void *hip_stream, msdr_ctx **out)
+{
+    if (!out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(MSDR_STATUS_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    }
+    if (device < 0 || device >= n) return fail(MSDR_STATUS_ARGUMENT_ERROR, "device %d out of range [0,%d)", device, n);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MSDR_STATUS_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", device,
+                    prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device));
+    msdr_ctx *c = new (std::nothrow) msdr_ctx();
+    if (!c) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
+    c->device = device;
+    c->owns_stream = (hip_stream == nullptr);
+    c->stream = (hipStream_t)hip_stream;
+    if (c->owns_stream) {
+        hipError_t e2 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e2 != hipSuccess) { delete c; return fail(MSDR_STATUS_HIP_ERROR, "hipStreamCreate: %s", hipGetErrorString(e2)); }
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" int msdr_ctx_destroy(msdr_ctx *ctx)
+{
+    if (!ctx) return 0;
+    if (int rc = bind(ctx)) return rc;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+extern "C" int msdr_ctx_synchronize(msdr_ctx *ctx)
+{
+    if (int rc = bind(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" void *msdr_ctx_stream(msdr_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int msdr_malloc(msdr_ctx *ctx, size_t bytes, void **d_ptr)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (!d_ptr) return fail(MSDR_STATUS_ARGUMENT_ERROR, "d_ptr is null");
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 16));
+    return 0;
+}
+extern "C" int msdr_free(msdr_ctx *ctx, void *d_ptr)
+{
+    if (int rc = bind(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_ptr));
+    return 0;
+}
+extern "C" int msdr_memcpy_h2d(msdr_ctx *ctx, void *d_dst, const void *src, size_t bytes)
+{
+    if (int rc = bind(ctx)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int msdr_memcpy_d2h(msdr_ctx *ctx, void *dst, const void *d_src, size_t bytes)
+{
+    if (int rc = bind(ctx)) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int msdr_memset(msdr_ctx *ctx, void *d_dst, int value, size_t bytes)
+{
+    if (int rc = bind(ctx)) return rc;
+    HIP_TRY(hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return 0;
+}
+
+// small RAII-free helper: device buffer filled from a host vector
+template <typename T>
+static int upload(msdr_ctx *ctx, const std::vector<T> &h, T **d)
+{
+    *d = nullptr;
+    HIP_TRY(hipMalloc((void **)d, std::max<size_t>(h.size() * sizeof(T), 16)));
+    if (!h.empty()) {
+        HIP_TRY(hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+template <typename T>
+static int dzalloc(msdr_ctx *ctx, size_t count, T **d)
+{
+    *d = nullptr;
+    size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    HIP_TRY(hipMalloc((void **)d, bytes));
+    HIP_TRY(hipMemsetAsync(*d, 0, bytes, ctx->stream));
+    return 0;
+}
+static int grid_1d(long long total, int block = 256)
+{
+    long long g = (total + block - 1) / block;
+    return (int)std::max<long long>(1, std::min<long long>(g, 256LL * 8));   // grid-stride above 2048 blocks
+}
+static int launch_check(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MSDR_STATUS_HIP_ERROR, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// designers (host)
+// ------------------------------------------------------------------------------------------------
+extern "C" void msdr_calc_FIR_coeffs(int16_t *coeffs, int numCoeffs, float32_t fc, float32_t Astop, int type, float dfc,
+                                     float Fsamprate)
+{
+    msdr::design::calc_fir_coeffs(coeffs, numCoeffs, fc, Astop, type, dfc, Fsamprate);
+}
+extern "C" int msdr_biquad_design(int kind, float frequency, float q_or_gain, float slope, double sample_rate, int32_t coef[5])
+{
+    if (!coef || kind < MSDR_BQ_LOWPASS || kind > MSDR_BQ_HIGHSHELF) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad biquad kind");
+    msdr::design::biquad_design(kind, frequency, q_or_gain, slope, sample_rate, coef);
+    return 0;
+}
+
+// tables for the parallel df1 stage (see BiquadStageTables)
+template <int L>
+static void make_stage_tables(const float *c, BiquadStageTables<L> *T)
+{
+    memset(T, 0, sizeof *T);
+    T->b0 = c[0]; T->b1 = c[1]; T->b2 = c[2]; T->a1 = c[3]; T->a2 = c[4];
+    const double a1 = c[3], a2 = c[4];
+    // alpha/beta: homogeneous responses to (y[-1], y[-2]) = (1,0) and (0,1)
+    double am1 = 1, am2 = 0, bm1 = 0, bm2 = 1, al[L], be[L];
+    for (int j = 0; j < L; j++) {
+        al[j] = a1 * am1 + a2 * am2; be[j] = a1 * bm1 + a2 * bm2;
+        am2 = am1; am1 = al[j]; bm2 = bm1; bm1 = be[j];
+        T->alpha[j] = (float)al[j]; T->beta[j] = (float)be[j];
+    }
+    double M[4] = {al[L - 1], be[L - 1], al[L - 2], be[L - 2]};
+    auto mul = [](const double *A, const double *B, double *C) {
+        double r[4] = {A[0] * B[0] + A[1] * B[2], A[0] * B[1] + A[1] * B[3], A[2] * B[0] + A[3] * B[2], A[2] * B[1] + A[3] * B[3]};
+        memcpy(C, r, sizeof r);
+    };
+    double P[4];
+    memcpy(P, M, sizeof P);
+    for (int k = 0; k < 6; k++) {
+        for (int i = 0; i < 4; i++) T->mpow[k][i] = (float)P[i];
+        mul(P, P, P);
+    }
+    for (int i = 0; i < 4; i++) T->m64[i] = (float)P[i];
+    double Q[4];
+    memcpy(Q, M, sizeof Q);
+    for (int l = 0; l < 64; l++) {
+        for (int i = 0; i < 4; i++) T->mlane[l][i] = (float)Q[i];
+        mul(Q, M, Q);
+    }
+}
+
+// largest pole radius of the cascade (y = ... + a1 y1 + a2 y2  =>  z^2 - a1 z - a2)
+static double max_pole_radius(const float *coeffs, int stages)
+{
+    double r = 0;
+    for (int s = 0; s < stages; s++) {
+        std::complex<double> a1 = coeffs[5 * s + 3], a2 = coeffs[5 * s + 4];
+        std::complex<double> disc = std::sqrt(a1 * a1 + 4.0 * a2);
+        r = std::max(r, std::max(std::abs((a1 + disc) / 2.0), std::abs((a1 - disc) / 2.0)));
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-stream FIR instances (arm_fir_fast_q15 / arm_fir_f32 mirrors)
+// ------------------------------------------------------------------------------------------------
+template <typename In, typename El>
+struct FirInst {
+    msdr_ctx *ctx;
+    uint32_t channels, ntaps, ntaps_pad, hist_len;
+    El *d_taps;
+    In *d_hist[2];
+    int cur;
+};
+struct msdr_fir_q15 : FirInst<int16_t, int32_t> {};
+struct msdr_fir_f32 : FirInst<float, float> {};
+
+template <typename Inst, typename In, typename El>
+static int fir_create(msdr_ctx *ctx, uint16_t numTaps, const In *pCoeffs, uint32_t channels, Inst **out)
+{
+    if (!out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "out is null");
+    *out = nullptr;
+    if (int rc = bind(ctx)) return rc;
+    if (!pCoeffs || numTaps == 0 || channels == 0) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad FIR arguments");
+    Inst *S = new (std::nothrow) Inst();
+    if (!S) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
+    S->ctx = ctx; S->channels = channels; S->ntaps = numTaps;
+    S->ntaps_pad = (numTaps + 3u) & ~3u;
+    S->hist_len = S->ntaps_pad - 1;
+    S->cur = 0; S->d_taps = nullptr; S->d_hist[0] = S->d_hist[1] = nullptr;
+    std::vector<El> t(S->ntaps_pad, (El)0);                    // zero taps in FRONT: they meet older samples
+    for (uint32_t k = 0; k < numTaps; k++) t[S->ntaps_pad - numTaps + k] = (El)pCoeffs[k];
+    int rc = upload(ctx, t, &S->d_taps);
+    if (!rc) rc = dzalloc(ctx, (size_t)channels * S->hist_len, &S->d_hist[0]);
+    if (!rc) rc = dzalloc(ctx, (size_t)channels * S->hist_len, &S->d_hist[1]);
+    if (rc) { hipFree(S->d_taps); hipFree(S->d_hist[0]); hipFree(S->d_hist[1]); delete S; return rc; }
+    *out = S;
+    return 0;
+}
+
+template <typename F, typename Inst, typename In>
+static int fir_process(Inst *S, const In *d_src, In *d_dst, uint32_t blockSize)
+{
+    if (!S) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
+    if (int rc = bind(S->ctx)) return rc;
+    if (blockSize == 0) return 0;
+    if (!d_src || !d_dst) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    if ((const void *)d_src == (const void *)d_dst)
+        return fail(MSDR_STATUS_ARGUMENT_ERROR, "FIR process is not in-place (the reference uses separate buffers, Minimal-SDR.ino:574-578)");
+    FirParams p;
+    p.x = d_src; p.y = d_dst; p.hist_in = S->d_hist[S->cur];
+    p.n = blockSize; p.channels = (int)S->channels;
+    // time segments: enough workgroups to fill the chip, no segment shorter than 4 tiles
+    long long tiles = ((long long)blockSize + kFirTile - 1) / kFirTile;
+    long long want = std::max<long long>(1, (2048 + S->channels - 1) / S->channels);
+    long long nseg = std::max<long long>(1, std::min<long long>(want, tiles / 4));
+    long long seg_tiles = (tiles + nseg - 1) / nseg;
+    p.seg_len = seg_tiles * kFirTile;
+    p.nseg = (int)((tiles + seg_tiles - 1) / seg_tiles);
+    p.ntaps_pad = (int)S->ntaps_pad; p.hist_len = (int)S->hist_len; p.taps = S->d_taps;
+    hipLaunchKernelGGL((fir_kernel<F>), dim3(S->channels * p.nseg), dim3(kThreads), fir_lds_bytes(p.ntaps_pad), S->ctx->stream, p);
+    if (int rc = launch_check("fir_kernel")) return rc;
+    hipLaunchKernelGGL((history_kernel<In>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
+                       d_src, (const In *)S->d_hist[S->cur], S->d_hist[S->cur ^ 1], (long long)blockSize, (int)S->hist_len,
+                       (int)S->channels);
+    if (int rc = launch_check("history_kernel")) return rc;
+    S->cur ^= 1;
+    return 0;
+}
+
+template <typename Inst>
+static int fir_reset(Inst *S)
+{
+    if (!S) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
+    if (int rc = bind(S->ctx)) return rc;
+    size_t bytes = (size_t)S->channels * S->hist_len * sizeof(*S->d_hist[0]);
+    HIP_TRY(hipMemsetAsync(S->d_hist[0], 0, bytes, S->ctx->stream));
+    HIP_TRY(hipMemsetAsync(S->d_hist[1], 0, bytes, S->ctx->stream));
+    return 0;
+}
+template <typename Inst>
+static int fir_destroy(Inst *S)
+{
+    if (!S) return 0;
+    if (int rc = bind(S->ctx)) return rc;
+    (void)hipStreamSynchronize(S->ctx->stream);
+    hipFree(S->d_taps); hipFree(S->d_hist[0]); hipFree(S->d_hist[1]);
+    delete S;
+    return 0;
+}
+
+extern "C" int msdr_fir_q15_create(msdr_ctx *ctx, uint16_t numTaps, const q15_t *pCoeffs, uint32_t channels, msdr_fir_q15 **out)
+{
+    if (out) *out = nullptr;
+    if (numTaps & 1u)   // arm_fir_init_q15.c:93-96
+        return fail(MSDR_STATUS_ARGUMENT_ERROR, "arm_fir_init_q15: numTaps must be even (got %u)", (unsigned)numTaps);
+    return fir_create<msdr_fir_q15, int16_t, int32_t>(ctx, numTaps, pCoeffs, channels, out);
+}
+extern "C" int msdr_fir_q15_process(msdr_fir_q15 *S, const q15_t *d_src, q15_t *d_dst, uint32_t blockSize)
+{
+    return fir_process<FirQ15>(S, d_src, d_dst, blockSize);
+}
+extern "C" int msdr_fir_q15_reset(msdr_fir_q15 *S) { return fir_reset(S); }
+extern "C" int msdr_fir_q15_destroy(msdr_fir_q15 *S) { return fir_destroy(S); }
+
+extern "C" int msdr_fir_f32_create(msdr_ctx *ctx, uint16_t numTaps, const float32_t *pCoeffs, uint32_t channels, msdr_fir_f32 **out)
+{
+    if (out) *out = nullptr;
+    return fir_create<msdr_fir_f32, float, float>(ctx, numTaps, pCoeffs, channels, out);
+}
+extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, float32_t *d_dst, uint32_t blockSize)
+{
+    return fir_process<FirF32>(S, d_src, d_dst, blockSize);
+}
+extern "C" int msdr_fir_f32_reset(msdr_fir_f32 *S) { return fir_reset(S); }
+extern "C" int msdr_fir_f32_destroy(msdr_fir_f32 *S) { return fir_destroy(S); }
+
+// ------------------------------------------------------------------------------------------------
+// arm_biquad_cascade_df1_f32 mirror
+// ------------------------------------------------------------------------------------------------
+struct msdr_biquad_df1_f32 {
+    msdr_ctx *ctx;
+    uint32_t channels, stages;
+    BiquadStageTables<kBqR> *d_tabs;
+    float *d_state;   // [channels][kMaxStages][4]
+};
+
+extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, const float32_t *pCoeffs, uint32_t channels,
+                                          msdr_biquad_df1_f32 **out)
+{
+    if (!out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "out is null");
+    *out = nullptr;
+    if (int rc = bind(ctx)) return rc;
+    if (numStages > kMaxStages) return fail(MSDR_STATUS_ARGUMENT_ERROR, "numStages %u > %d", (unsigned)numStages, kMaxStages);
+    if ((numStages && !pCoeffs) || channels == 0) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad biquad arguments");
+    msdr_biquad_df1_f32 *S = new (std::nothrow) msdr_biquad_df1_f32();
+    if (!S) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
+    S->ctx = ctx; S->channels = channels; S->stages = numStages; S->d_tabs = nullptr; S->d_state = nullptr;
+    std::vector<BiquadStageTables<kBqR>> tabs(std::max<int>(numStages, 1));
+    for (int s = 0; s < numStages; s++) make_stage_tables<kBqR>(pCoeffs + 5 * s, &tabs[s]);
+    int rc = upload(ctx, tabs, &S->d_tabs);
+    if (!rc) rc = dzalloc(ctx, (size_t)channels * kMaxStages * 4, &S->d_state);
+    if (rc) { hipFree(S->d_tabs); hipFree(S->d_state); delete S; return rc; }
+    *out = S;
+    return 0;
+}
+extern "C" int msdr_biquad_df1_f32_process(msdr_biquad_df1_f32 *S, const float32_t *d_src, float32_t *d_dst, uint32_t blockSize)
+{
+    if (!S) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
+    if (int rc = bind(S->ctx)) return rc;
+    if (blockSize == 0) return 0;
+    if (!d_src || !d_dst) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    hipLaunchKernelGGL(biquad_df1_kernel, dim3(S->channels), dim3(kThreads), 0, S->ctx->stream, d_src, d_dst,
+                       (long long)blockSize, (int)S->stages, (const BiquadStageTables<kBqR> *)S->d_tabs, S->d_state);
+    return launch_check("biquad_df1_kernel");
+}
+extern "C" int msdr_biquad_df1_f32_reset(msdr_biquad_df1_f32 *S)
+{
+    if (!S) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
+    if (int rc = bind(S->ctx)) return rc;
+    HIP_TRY(hipMemsetAsync(S->d_state, 0, (size_t)S->channels * kMaxStages * 4 * sizeof(float), S->ctx->stream));
+    return 0;
+}
+extern "C" int msdr_biquad_df1_f32_destroy(msdr_biquad_df1_f32 *S)
+{
+    if (!S) return 0;
+    if (int rc = bind(S->ctx)) return rc;
+    (void)hipStreamSynchronize(S->ctx->stream);
+    hipFree(S->d_tabs); hipFree(S->d_state);
+    delete S;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Teensy AudioFilterBiquad mirror
+// ------------------------------------------------------------------------------------------------
+struct msdr_biquad_q15 {
+    msdr_ctx *ctx;
+    uint32_t channels;
+    int *d_defs;      // [channels][32]
+};
+
+// filter_biquad.cpp:84-100 applied to every channel's record
+__global__ void tbq_set_coef_kernel(int *defs, int channels, int stage, int c0, int c1, int c2, int c3, int c4)
+{
+    for (int ch = blockIdx.x * blockDim.x + threadIdx.x; ch < channels; ch += gridDim.x * blockDim.x) {
+        int *dest = defs + (long long)ch * 32 + (stage << 3);
+        if (stage > 0) dest[-1] |= 0x80000000;
+        dest[0] = c0; dest[1] = c1; dest[2] = c2;
+        dest[3] = (int)(0u - (unsigned)c3);
+        dest[4] = (int)(0u - (unsigned)c4);
+        dest[7] &= 0x80000000;
+    }
+}
+
+extern "C" int msdr_biquad_q15_create(msdr_ctx *ctx, uint32_t channels, msdr_biquad_q15 **out)
+{
+    if (!out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "out is null");
+    *out = nullptr;
+    if (int rc = bind(ctx)) return rc;
+    if (channels == 0) return fail(MSDR_STATUS_ARGUMENT_ERROR, "channels == 0");
+    msdr_biquad_q15 *S = new (std::nothrow) msdr_biquad_q15();
+    if (!S) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
+    S->ctx = ctx; S->channels = channels; S->d_defs = nullptr;
+    if (int rc = dzalloc(ctx, (size_t)channels * 32, &S->d_defs)) { delete S; return rc; }   // h:36-39: passes nothing
+    *out = S;
+    return 0;
+}
+extern "C" int msdr_biquad_q15_set_coefficients(msdr_biquad_q15 *S, uint32_t stage, const int32_t coef[5])
+{
+    if (!S || !coef) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    if (stage >= 4) return 0;                                   // filter_biquad.cpp:86: silently ignored
+    if (int rc = bind(S->ctx)) return rc;
+    hipLaunchKernelGGL(tbq_set_coef_kernel, dim3(grid_1d(S->channels)), dim3(256), 0, S->ctx->stream, S->d_defs, (int)S->channels,
+                       (int)stage, coef[0], coef[1], coef[2], coef[3], coef[4]);
+    return launch_check("tbq_set_coef_kernel");
+}
+extern "C" int msdr_biquad_q15_update(msdr_biquad_q15 *S, q15_t *d_data, uint32_t blockSize)
+{
+    if (!S) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
+    if (int rc = bind(S->ctx)) return rc;
+    if (blockSize == 0) return 0;
+    if (!d_data) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    if (blockSize & 1u) return fail(MSDR_STATUS_LENGTH_ERROR, "AudioFilterBiquad processes sample pairs: blockSize must be even");
+    hipLaunchKernelGGL(biquad_teensy_kernel, dim3((S->channels + 63) / 64), dim3(64), 0, S->ctx->stream, d_data, S->d_defs,
+                       (int)S->channels, (long long)blockSize);
+    return launch_check("biquad_teensy_kernel");
+}
+extern "C" int msdr_biquad_q15_get_definition(msdr_biquad_q15 *S, uint32_t channel, int32_t definition[32])
+{
+    if (!S || !definition || channel >= S->channels) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad argument");
+    return msdr_memcpy_d2h(S->ctx, definition, S->d_defs + (size_t)channel * 32, 32 * sizeof(int32_t));
+}
+extern "C" int msdr_biquad_q15_destroy(msdr_biquad_q15 *S)
+{
+    if (!S) return 0;
+    if (int rc = bind(S->ctx)) return rc;
+    (void)hipStreamSynchronize(S->ctx->stream);
+    hipFree(S->d_defs);
+    delete S;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stateless stages
+// ------------------------------------------------------------------------------------------------
+extern "C" int msdr_mix_fs4_q15(msdr_ctx *ctx, const q15_t *d_x, q15_t *d_i, q15_t *d_q, uint32_t channels, uint32_t blockSize)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (!d_x || !d_i || !d_q) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    long long total = (long long)channels * blockSize;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(mix_fs4_q15_kernel, dim3(grid_1d(total)), dim3(256), 0, ctx->stream, d_x, d_i, d_q, total, (int)blockSize);
+    return launch_check("mix_fs4_q15_kernel");
+}
+
+template <typename T, typename K>
+static int freqconv_common(msdr_ctx *ctx, T *d_i, T *d_q, const T *osc_i, const T *osc_q, uint32_t osc_len, int dir, int pass,
+                           uint32_t channels, uint32_t blockSize, K kernel, const char *name)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (!d_i || !d_q) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");   // freq_conv.cpp:40-47: nothing transmitted
+    if (!pass) return 0;                                                        // :49-56: forwarded untouched
+    if (!osc_i || !osc_q || osc_len == 0) return fail(MSDR_STATUS_ARGUMENT_ERROR, "oscillator tables missing");
+    long long total = (long long)channels * blockSize;
+    if (total == 0) return 0;
+    std::vector<T> hi(osc_i, osc_i + osc_len), hq(osc_q, osc_q + osc_len);
+    T *di = nullptr, *dq = nullptr;
+    int rc = upload(ctx, hi, &di);
+    if (!rc) rc = upload(ctx, hq, &dq);
+    if (!rc) {
+        hipLaunchKernelGGL(kernel, dim3(grid_1d(total)), dim3(256), 0, ctx->stream, d_i, d_q, (const T *)di, (const T *)dq,
+                           (int)osc_len, dir ? 1 : 0, total, (int)blockSize);
+        rc = launch_check(name);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    hipFree(di); hipFree(dq);
+    return rc;
+}
+extern "C" int msdr_freqconv_q15(msdr_ctx *ctx, q15_t *d_i, q15_t *d_q, const q15_t *osc_i, const q15_t *osc_q, uint32_t osc_len,
+                                 int dir, int pass, uint32_t channels, uint32_t blockSize)
+{
+    return freqconv_common<short>(ctx, d_i, d_q, osc_i, osc_q, osc_len, dir, pass, channels, blockSize, freqconv_q15_kernel,
+                                  "freqconv_q15_kernel");
+}
+extern "C" int msdr_freqconv_f32(msdr_ctx *ctx, float32_t *d_i, float32_t *d_q, const float32_t *osc_i, const float32_t *osc_q,
+                                 uint32_t osc_len, int dir, int pass, uint32_t channels, uint32_t blockSize)
+{
+    return freqconv_common<float>(ctx, d_i, d_q, osc_i, osc_q, osc_len, dir, pass, channels, blockSize, freqconv_f32_kernel,
+                                  "freqconv_f32_kernel");
+}
+extern "C" int msdr_demod_q15(msdr_ctx *ctx, int mode, const int32_t *d_mode, int sqrt_kind, const q15_t *d_i, const q15_t *d_q,
+                              q15_t *d_out, uint32_t channels, uint32_t blockSize)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (!d_i || !d_q || !d_out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    long long total = (long long)channels * blockSize;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(demod_q15_kernel, dim3(grid_1d(total)), dim3(256), 0, ctx->stream, mode, d_mode, sqrt_kind, d_i, d_q, d_out,
+                       total, (int)blockSize);
+    return launch_check("demod_q15_kernel");
+}
+extern "C" int msdr_demod_f32(msdr_ctx *ctx, int mode, const int32_t *d_mode, const float32_t *d_i, const float32_t *d_q,
+                              float32_t *d_out, uint32_t channels, uint32_t blockSize)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (!d_i || !d_q || !d_out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    long long total = (long long)channels * blockSize;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(demod_f32_kernel, dim3(grid_1d(total)), dim3(256), 0, ctx->stream, mode, d_mode, d_i, d_q, d_out, total,
+                       (int)blockSize);
+    return launch_check("demod_f32_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused chain
+// ------------------------------------------------------------------------------------------------
+struct msdr_chain {
+    msdr_ctx *ctx;
+    int arith, mixer, sqrt_kind;
+    uint32_t channels, ntaps, ntaps_pad, hist_len, tapsets;
+    uint32_t osc_len;
+    float in_scale;
+    uint32_t nstages;                 // F32
+    uint32_t nnodes;                  // Q15
+    uint32_t time_segments, warmup_cfg;
+    double pole_radius;
+    void *d_taps, *d_osc;
+    int *d_mode, *d_tapset;
+    int16_t *d_hist[2];
+    int cur;
+    long long phase;                  // absolute sample index modulo the NCO period
+    BiquadStageTables<kChainR> *d_bq;
+    float *d_bq_state;
+    msdr_biquad_q15 *nodes[2];
+    msdr_chain_info info;
+    // optional per-launch timing of the main kernel
+    bool timing;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double timed_ms;
+    uint64_t timed_launches;
+};
+
+static void chain_free(msdr_chain *c)
+{
+    if (!c) return;
+    hipFree(c->d_taps); hipFree(c->d_osc); hipFree(c->d_mode); hipFree(c->d_tapset);
+    hipFree(c->d_hist[0]); hipFree(c->d_hist[1]); hipFree(c->d_bq); hipFree(c->d_bq_state);
+    for (int k = 0; k < 2; k++) if (c->nodes[k]) msdr_biquad_q15_destroy(c->nodes[k]);
+    for (auto &e : c->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    delete c;
+}
+
+extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_chain **out)
+{
+    if (!out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "out is null");
+    *out = nullptr;
+    if (int rc = bind(ctx)) return rc;
+    if (!cfg || cfg->struct_size != sizeof(msdr_chain_config))
+        return fail(MSDR_STATUS_ARGUMENT_ERROR, "msdr_chain_config.struct_size mismatch (got %u, want %zu)",
+                    cfg ? cfg->struct_size : 0u, sizeof(msdr_chain_config));
+    const bool f32 = (cfg->arith == MSDR_ARITH_F32);
+    if (cfg->arith != MSDR_ARITH_F32 && cfg->arith != MSDR_ARITH_Q15) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad arith");
+    if (cfg->channels == 0) return fail(MSDR_STATUS_ARGUMENT_ERROR, "channels == 0");
+    if (cfg->mixer != MSDR_MIXER_FS4 && cfg->mixer != MSDR_MIXER_NCO) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad mixer");
+    if (cfg->num_taps == 0 || cfg->num_taps > 4096) return fail(MSDR_STATUS_ARGUMENT_ERROR, "num_taps must be 1..4096");
+    if (!f32 && (cfg->num_taps & 1u))
+        return fail(MSDR_STATUS_ARGUMENT_ERROR, "arm_fir_init_q15: numTaps must be even (got %u)", cfg->num_taps);
+    if (cfg->num_tapsets == 0 || cfg->num_tapsets > MSDR_MAX_TAPSETS) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad num_tapsets");
+    for (uint32_t s = 0; s < cfg->num_tapsets; s++)
+        if (!cfg->coeffs_i[s] || !cfg->coeffs_q[s]) return fail(MSDR_STATUS_ARGUMENT_ERROR, "tap set %u missing", s);
+    if (cfg->mixer == MSDR_MIXER_NCO && (!cfg->osc_i || !cfg->osc_q || cfg->osc_len == 0))
+        return fail(MSDR_STATUS_ARGUMENT_ERROR, "NCO mixer needs osc tables");
+    if (f32 && cfg->num_biquad_stages > kMaxStages) return fail(MSDR_STATUS_ARGUMENT_ERROR, "num_biquad_stages > 4");
+    if (f32 && cfg->num_biquad_stages && !cfg->biquad_coeffs) return fail(MSDR_STATUS_ARGUMENT_ERROR, "biquad_coeffs missing");
+    if (!f32 && cfg->num_biquad_nodes > 2) return fail(MSDR_STATUS_ARGUMENT_ERROR, "num_biquad_nodes > 2");
+    auto mode_ok = [](int m) { return m >= MSDR_MODE_SYNCAM && m <= MSDR_MODE_CW; };
+    if (!mode_ok(cfg->default_mode)) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad default_mode");
+
+    msdr_chain *c = new (std::nothrow) msdr_chain();
+    if (!c) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
+    c->ctx = ctx; c->arith = cfg->arith; c->mixer = cfg->mixer; c->sqrt_kind = cfg->sqrt_kind;
+    c->channels = cfg->channels; c->ntaps = cfg->num_taps; c->ntaps_pad = (cfg->num_taps + 3u) & ~3u;
+    c->hist_len = c->ntaps_pad - 1; c->tapsets = cfg->num_tapsets;
+    c->osc_len = (cfg->mixer == MSDR_MIXER_NCO) ? cfg->osc_len : 4;
+    c->in_scale = (cfg->in_scale == 0.0f) ? 1.0f / 32768.0f : cfg->in_scale;
+    c->nstages = f32 ? cfg->num_biquad_stages : 0;
+    c->nnodes = f32 ? 0 : cfg->num_biquad_nodes;
+    c->time_segments = cfg->time_segments; c->warmup_cfg = cfg->biquad_warmup;
+    c->pole_radius = c->nstages ? max_pole_radius(cfg->biquad_coeffs, (int)c->nstages) : 0.0;
+    c->cur = 0; c->phase = 0; c->timing = false; c->timed_ms = 0; c->timed_launches = 0;
+    memset(&c->info, 0, sizeof c->info);
+
+    int rc = 0;
+    // taps: pairs {hI[k], hQ[k]}, zero-padded in FRONT to a multiple of 4
+    const uint32_t np = c->ntaps_pad, off = np - c->ntaps;
+    if (f32) {
+        std::vector<float> t((size_t)c->tapsets * np * 2, 0.0f);
+        for (uint32_t s = 0; s < c->tapsets; s++)
+            for (uint32_t k = 0; k < c->ntaps; k++) {
+                t[((size_t)s * np + off + k) * 2 + 0] = ((const float *)cfg->coeffs_i[s])[k];
+                t[((size_t)s * np + off + k) * 2 + 1] = ((const float *)cfg->coeffs_q[s])[k];
+            }
+        rc = upload(ctx, t, (float **)&c->d_taps);
+    } else {
+        std::vector<int32_t> t((size_t)c->tapsets * np * 2, 0);
+        for (uint32_t s = 0; s < c->tapsets; s++)
+            for (uint32_t k = 0; k < c->ntaps; k++) {
+                t[((size_t)s * np + off + k) * 2 + 0] = ((const int16_t *)cfg->coeffs_i[s])[k];
+                t[((size_t)s * np + off + k) * 2 + 1] = ((const int16_t *)cfg->coeffs_q[s])[k];
+            }
+        rc = upload(ctx, t, (int32_t **)&c->d_taps);
+    }
+    // osc pairs {osc_q ("cos"), osc_i ("sin")}
+    if (!rc) {
+        if (f32) {
+            std::vector<float> o((size_t)c->osc_len * 2, 0.0f);
+            if (cfg->mixer == MSDR_MIXER_NCO)
+                for (uint32_t k = 0; k < c->osc_len; k++) { o[2 * k] = ((const float *)cfg->osc_q)[k]; o[2 * k + 1] = ((const float *)cfg->osc_i)[k]; }
+            rc = upload(ctx, o, (float **)&c->d_osc);
+        } else {
+            std::vector<int32_t> o((size_t)c->osc_len * 2, 0);
+            if (cfg->mixer == MSDR_MIXER_NCO)
+                for (uint32_t k = 0; k < c->osc_len; k++) { o[2 * k] = ((const int16_t *)cfg->osc_q)[k]; o[2 * k + 1] = ((const int16_t *)cfg->osc_i)[k]; }
+            rc = upload(ctx, o, (int32_t **)&c->d_osc);
+        }
+    }
+    if (!rc) {
+        std::vector<int> m(c->channels), ts(c->channels);
+        for (uint32_t ch = 0; ch < c->channels && !rc; ch++) {
+            m[ch] = cfg->mode ? cfg->mode[ch] : cfg->default_mode;
+            ts[ch] = cfg->tapset ? cfg->tapset[ch] : 0;
+            if (!mode_ok(m[ch]) || ts[ch] < 0 || (uint32_t)ts[ch] >= c->tapsets)
+                rc = fail(MSDR_STATUS_ARGUMENT_ERROR, "channel %u: bad mode/tapset", ch);
+        }
+        if (!rc) rc = upload(ctx, m, &c->d_mode);
+        if (!rc) rc = upload(ctx, ts, &c->d_tapset);
+    }
+    if (!rc) rc = dzalloc(ctx, (size_t)c->channels * c->hist_len, &c->d_hist[0]);
+    if (!rc) rc = dzalloc(ctx, (size_t)c->channels * c->hist_len, &c->d_hist[1]);
+    if (!rc && f32) {
+        std::vector<BiquadStageTables<kChainR>> tabs(std::max<uint32_t>(c->nstages, 1));
+        for (uint32_t s = 0; s < c->nstages; s++) make_stage_tables<kChainR>(cfg->biquad_coeffs + 5 * s, &tabs[s]);
+        rc = upload(ctx, tabs, &c->d_bq);
+        if (!rc) rc = dzalloc(ctx, (size_t)c->channels * kMaxStages * 4, &c->d_bq_state);
+    }
+    for (uint32_t k = 0; k < c->nnodes && !rc; k++) {
+        if (cfg->node_stages[k] < 1 || cfg->node_stages[k] > 4 || !cfg->node_coefs[k]) { rc = fail(MSDR_STATUS_ARGUMENT_ERROR, "biquad node %u misconfigured", k); break; }
+        rc = msdr_biquad_q15_create(ctx, c->channels, &c->nodes[k]);
+        for (uint32_t s = 0; s < cfg->node_stages[k] && !rc; s++)
+            rc = msdr_biquad_q15_set_coefficients(c->nodes[k], s, cfg->node_coefs[k] + 5 * s);
+    }
+    if (rc) { chain_free(c); return rc; }
+    *out = c;
+    return 0;
+}
+
+extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_audio, uint64_t n_samples)
+{
+    if (!c) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null chain");
+    if (int rc = bind(c->ctx)) return rc;
+    if (n_samples == 0) return 0;
+    if (!d_if || !d_audio) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    if (n_samples > (1ull << 31) - 4096) return fail(MSDR_STATUS_LENGTH_ERROR, "n_samples too large for one call");
+    const bool f32 = (c->arith == MSDR_ARITH_F32);
+    if (!f32 && c->nnodes && (n_samples & 1u))
+        return fail(MSDR_STATUS_LENGTH_ERROR, "AudioFilterBiquad processes sample pairs: n_samples must be even");
+
+    ChainParams p;
+    memset(&p, 0, sizeof p);
+    p.x = d_if; p.out = d_audio; p.hist_in = c->d_hist[c->cur]; p.hist_out = c->d_hist[c->cur ^ 1];
+    p.n = (long long)n_samples; p.channels = (int)c->channels;
+    p.ntaps_pad = (int)c->ntaps_pad; p.hist_len = (int)c->hist_len; p.taps = c->d_taps;
+    p.chan_mode = c->d_mode; p.chan_tapset = c->d_tapset; p.mixer = c->mixer; p.osc = c->d_osc; p.osc_len = (int)c->osc_len;
+    p.phase0 = (int)c->phase; p.in_scale = c->in_scale; p.sqrt_kind = c->sqrt_kind;
+    p.nstages = (int)c->nstages; p.bq = c->d_bq; p.bq_state = c->d_bq_state;
+
+    // ---- time segmentation (DESIGN.md "IIR along time") ------------------------------------------
+    const long long tiles = ((long long)n_samples + kChainTile - 1) / kChainTile;
+    long long warm_tiles = 0;
+    bool can_split = true;
+    if (c->nstages) {
+        long long w = c->warmup_cfg;
+        if (w == 0) {
+            if (c->pole_radius >= 0.99999) can_split = false;        // marginal/unstable: never re-converges
+            else if (c->pole_radius > 0) w = (long long)std::ceil(std::log(1e-10) / std::log(c->pole_radius)) + 64 * c->nstages;
+        }
+        warm_tiles = (w + kChainTile - 1) / kChainTile;
+        if (warm_tiles > 64) can_split = false;
+    }
+    long long nseg = 1;
+    if (c->time_segments == 1 || !can_split) nseg = 1;
+    else {
+        long long min_seg_tiles = std::max<long long>(4, 32 * warm_tiles);   // <= ~3 % redone work
+        long long max_nseg = std::max<long long>(1, tiles / min_seg_tiles);
+        long long want = c->time_segments > 1 ? c->time_segments : std::max<long long>(1, (2048 + c->channels - 1) / c->channels);
+        nseg = std::max<long long>(1, std::min(want, max_nseg));
+    }
+    long long seg_tiles = (tiles + nseg - 1) / nseg;
+    nseg = (tiles + seg_tiles - 1) / seg_tiles;
+    p.nseg = (int)nseg; p.seg_len = seg_tiles * kChainTile; p.warm = (int)(nseg > 1 ? warm_tiles * kChainTile : 0);
+
+    const size_t lds = chain_lds_bytes(p.ntaps_pad);
+    const unsigned grid = (unsigned)(c->channels * nseg);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing && c->events.size() < 8192) {
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, c->ctx->stream));
+    }
+    if (f32) hipLaunchKernelGGL((chain_kernel<ArithF32>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p);
+    else     hipLaunchKernelGGL((chain_kernel<ArithQ15>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p);
+    if (int rc = launch_check("chain_kernel")) return rc;
+    if (e0) { HIP_TRY(hipEventRecord(e1, c->ctx->stream)); c->events.emplace_back(e0, e1); }
+
+    for (uint32_t k = 0; k < c->nnodes; k++)
+        if (int rc = msdr_biquad_q15_update(c->nodes[k], (q15_t *)d_audio, (uint32_t)n_samples)) return rc;
+
+    hipLaunchKernelGGL((history_kernel<int16_t>), dim3(grid_1d((long long)c->channels * c->hist_len)), dim3(256), 0, c->ctx->stream,
+                       d_if, (const int16_t *)c->d_hist[c->cur], c->d_hist[c->cur ^ 1], (long long)n_samples, (int)c->hist_len,
+                       (int)c->channels);
+    if (int rc = launch_check("history_kernel")) return rc;
+    c->cur ^= 1;
+    c->phase = (c->phase + (long long)(n_samples % c->osc_len)) % c->osc_len;
+
+    snprintf(c->info.kernel, sizeof c->info.kernel, "%s", f32 ? "chain_kernel<ArithF32>" : "chain_kernel<ArithQ15>");
+    c->info.grid = grid; c->info.block = kThreads; c->info.lds_bytes = (uint32_t)lds;
+    c->info.time_segments = (uint32_t)nseg; c->info.warmup = (uint32_t)p.warm; c->info.tile = kChainTile;
+    c->info.taps_padded = c->ntaps_pad;
+    return 0;
+}
+
+extern "C" int msdr_chain_reset(msdr_chain *c)
+{
+    if (!c) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null chain");
+    if (int rc = bind(c->ctx)) return rc;
+    size_t hb = (size_t)c->channels * c->hist_len * sizeof(int16_t);
+    HIP_TRY(hipMemsetAsync(c->d_hist[0], 0, hb, c->ctx->stream));
+    HIP_TRY(hipMemsetAsync(c->d_hist[1], 0, hb, c->ctx->stream));
+    if (c->d_bq_state) HIP_TRY(hipMemsetAsync(c->d_bq_state, 0, (size_t)c->channels * kMaxStages * 4 * sizeof(float), c->ctx->stream));
+    // the reference never clears biquad history on retune (filter_biquad.cpp:95-97); init_FIR() only zeroes the FIR state.
+    c->phase = 0;
+    return 0;
+}
+
+extern "C" int msdr_chain_set_mode(msdr_chain *c, uint32_t channel, int32_t mode, int32_t tapset)
+{
+    if (!c) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null chain");
+    if (int rc = bind(c->ctx)) return rc;
+    if (channel >= c->channels || mode < MSDR_MODE_SYNCAM || mode > MSDR_MODE_CW || tapset < 0 || (uint32_t)tapset >= c->tapsets)
+        return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad channel/mode/tapset");
+    HIP_TRY(hipMemcpyAsync(c->d_mode + channel, &mode, sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_tapset + channel, &tapset, sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    return 0;
+}
+
+extern "C" int msdr_chain_destroy(msdr_chain *c)
+{
+    if (!c) return 0;
+    if (int rc = bind(c->ctx)) return rc;
+    (void)hipStreamSynchronize(c->ctx->stream);
+    chain_free(c);
+    return 0;
+}
+
+extern "C" int msdr_chain_get_info(msdr_chain *c, msdr_chain_info *info)
+{
+    if (!c || !info) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    *info = c->info;
+    return 0;
+}
+
+extern "C" int msdr_chain_enable_timing(msdr_chain *c, int on)
+{
+    if (!c) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null chain");
+    c->timing = on != 0;
+    return 0;
+}
+
+extern "C" int msdr_chain_get_kernel_time(msdr_chain *c, double *total_ms, uint64_t *launches, int reset)
+{
+    if (!c) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null chain");
+    if (int rc = bind(c->ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    for (auto &e : c->events) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+        c->timed_ms += ms; c->timed_launches++;
+        hipEventDestroy(e.first); hipEventDestroy(e.second);
+    }
+    c->events.clear();
+    if (total_ms) *total_ms = c->timed_ms;
+    if (launches) *launches = c->timed_launches;
+    if (reset) { c->timed_ms = 0; c->timed_launches = 0; }
+    return 0;
+}

@@ -1,0 +1,134 @@
+// msdr_design.cpp -- see msdr_design.h.  The results are truncated to integers, so operand types
+// (float vs double) follow the reference expression by expression; compile with -ffp-contract=off.
+#include "msdr_design.h"
+
+#include <cmath>
+
+namespace msdr {
+namespace design {
+
+namespace {
+// `PI` as the vendored sources define it (src/CMSIS_5/arm_math.h:365-367, float fallback).
+constexpr float kPi = 3.14159265358979f;
+constexpr float kHalfPi = kPi / 2;
+
+inline int16_t to_q15(float v) { return (int16_t)(int32_t)v; }
+
+// Kaiser window value at normalised position x in [-1,1)  (.ino:852-853)
+inline float kaiser(float beta, float x, float izb) { return izero(beta * sqrtf(1.0f - x * x)) / izb; }
+
+// Kaiser beta from the stop-band attenuation (.ino:801-806); the literals are doubles in the sketch
+float kaiser_beta(float astop)
+{
+    if (astop < 20.96) return 0.0f;
+    if (astop >= 50.0) return (float)(0.1102 * (astop - 8.71));
+    return (float)(0.5842 * powf((float)(astop - 20.96), (float)0.4) + 0.07886 * (astop - 20.96));
+}
+}  // namespace
+
+// modified Bessel function I0 by its power series (.ino:883-899)
+float izero(float x)
+{
+    const float errorlimit = 1e-9;
+    const float half = (float)(x / 2.0);
+    float sum = 1.0f, term = 1.0f, k = 1.0f;
+    do {
+        float q = half / k;
+        q *= q;
+        term *= q;
+        sum += term;
+        k = (float)(k + 1.0);
+    } while (term >= errorlimit * sum);
+    return sum;
+}
+
+// sin(m*pi/2*fc) / (m*pi/2*fc), m stepping by 2 (.ino:874-881)
+float sinc_half_pi(int m, float fc)
+{
+    if (m == 0) return 1.0f;
+    const float x = m * kHalfPi;
+    return sinf(x * fc) / (fc * x);
+}
+
+void calc_fir_coeffs(int16_t *coeffs, int num_coeffs, float fc, float astop, int type, float dfc, float fsamp)
+{
+    fc = fc / fsamp;
+    dfc = dfc / fsamp;
+    const float beta = kaiser_beta(astop);
+    const float izb = izero(beta);
+    const int even = 2 * (num_coeffs / 2);
+    float fcf;
+    int nc;
+    switch (type) {
+    case 0: fcf = (float)(fc * 2.0); nc = num_coeffs; break;     // low-pass (.ino:812-815)
+    case 1: fcf = -fc; nc = even; break;                          // high-pass
+    case 2:
+    case 3: fcf = dfc; nc = even; break;                          // band-pass / notch
+    case 4: {                                                     // Hilbert (.ino:828-845), interleaved 2*nc layout
+        nc = even;
+        for (int i = 0; i < 2 * (nc - 1); i++) coeffs[i] = 0;
+        coeffs[nc] = 1;
+        for (int i = 1; i < nc + 1; i += 2) {
+            if (2 * i == nc) continue;
+            const float w = kaiser(beta, (float)(2 * i - nc) / (float)nc, izb);
+            coeffs[2 * i + 1] = to_q15(32767 * (1.0f / (kHalfPi * (float)(i - nc / 2)) * w));
+        }
+        return;
+    }
+    default: return;
+    }
+    int j = 0;
+    for (int i = -nc; i < nc; i += 2, j++) {                      // windowed sinc (.ino:850-855)
+        const float w = kaiser(beta, (float)i / (float)nc, izb);
+        coeffs[j] = to_q15(fcf * sinc_half_pi(i, fcf) * w * 32767);
+    }
+    if (type == 1) {
+        coeffs[nc / 2] += 1;
+    } else if (type == 2 || type == 3) {                          // modulate to the centre frequency (.ino:861-869)
+        const float gain = (type == 2) ? 2.0f : -2.0f;
+        for (j = 0; j < nc + 1; j++) coeffs[j] = to_q15(coeffs[j] * (gain * cosf(kHalfPi * (2 * j - nc) * fc)));
+        if (type == 3) coeffs[nc / 2] += 1;
+    }
+}
+
+void biquad_design(int kind, float frequency, float q_or_gain, float slope, double sample_rate, int32_t coef[5])
+{
+    const double w0 = frequency * (2 * 3.141592654 / sample_rate);
+    const double sn = sin(w0), cs = cos(w0);
+    if (kind <= 3) {                                              // low/high/band-pass, notch: h:56-111
+        const double alpha = sn / ((double)q_or_gain * 2.0);
+        const double scale = 1073741824.0 / (1.0 + alpha);
+        double b0, b1, b2;
+        if (kind == 0)      { b0 = ((1.0 - cs) / 2.0) * scale; b1 = (1.0 - cs) * scale;  b2 = NAN; }
+        else if (kind == 1) { b0 = ((1.0 + cs) / 2.0) * scale; b1 = -(1.0 + cs) * scale; b2 = NAN; }
+        else if (kind == 2) { b0 = alpha * scale;              b1 = 0.0;                 b2 = (-alpha) * scale; }
+        else                { b0 = scale;                      b1 = (-2.0 * cs) * scale; b2 = NAN; }
+        coef[0] = (int32_t)b0;
+        coef[1] = (int32_t)b1;
+        coef[2] = std::isnan(b2) ? coef[0] : (int32_t)b2;         // the header copies coef[0] (already truncated)
+        coef[3] = (int32_t)((-2.0 * cs) * scale);
+        coef[4] = (int32_t)((1.0 - alpha) * scale);
+        return;
+    }
+    const double a = pow(10.0, q_or_gain / 40.0);                  // shelves: h:112-149
+    const double sinsq = sn * sqrt((pow(a, 2.0) + 1.0) * (1.0 / slope - 1.0) + 2.0 * a);
+    const double am = (a - 1.0) * cs, ap = (a + 1.0) * cs;
+    if (kind == 4) {
+        const double scale = 1073741824.0 / ((a + 1.0) + am + sinsq);
+        coef[0] = (int32_t)(a * ((a + 1.0) - am + sinsq) * scale);
+        coef[1] = (int32_t)(2.0 * a * ((a - 1.0) - ap) * scale);
+        coef[2] = (int32_t)(a * ((a + 1.0) - am - sinsq) * scale);
+        coef[3] = (int32_t)(-2.0 * ((a - 1.0) + ap) * scale);
+        coef[4] = (int32_t)(((a + 1.0) + am - sinsq) * scale);
+    } else {
+        const double scale = 1073741824.0 / ((a + 1.0) - am + sinsq);
+        coef[0] = (int32_t)(a * ((a + 1.0) + am + sinsq) * scale);
+        coef[1] = (int32_t)(-2.0 * a * ((a - 1.0) + ap) * scale);
+        coef[2] = (int32_t)(a * ((a + 1.0) + am - sinsq) * scale);
+        coef[3] = (int32_t)(2.0 * ((a - 1.0) - ap) * scale);
+        coef[4] = (int32_t)(((a + 1.0) - am - sinsq) * scale);
+    }
+}
+
+}  // namespace design
+}  // namespace msdr

@@ -1,0 +1,351 @@
+"""ctypes binding of the C ABI in include/msdr.h (minimal-sdr_amd/lib/libmsdr.so).
+
+This is the stub a Python caller binds; the product is the shared library.  Used by tests/ and
+bench.py.  It never falls back to a CPU implementation: if the library or a gfx950 device is
+missing, construction raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmsdr.so")
+
+MODE_SYNCAM, MODE_AM, MODE_LSB, MODE_USB, MODE_CW = 0, 1, 2, 3, 4
+SQRT_F32, SQRT_Q31 = 0, 1
+MIXER_FS4, MIXER_NCO = 0, 1
+ARITH_Q15, ARITH_F32 = 0, 1
+BQ_LOWPASS, BQ_HIGHPASS, BQ_BANDPASS, BQ_NOTCH, BQ_LOWSHELF, BQ_HIGHSHELF = range(6)
+AUDIO_SAMPLE_RATE_EXACT = 44117.64706
+MAX_TAPSETS = 8
+CHAIN_NO_TAP_FOLDING = 1
+
+STATUS_ARGUMENT_ERROR, STATUS_LENGTH_ERROR, STATUS_NO_DEVICE = -1, -2, -100
+
+_p = C.c_void_p
+
+
+class MsdrError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__("msdr status %d: %s" % (status, text))
+        self.status = status
+
+
+class ChainConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("arith", C.c_int32), ("channels", C.c_uint32), ("mixer", C.c_int32),
+                ("num_taps", C.c_uint32), ("num_tapsets", C.c_uint32),
+                ("coeffs_i", _p * MAX_TAPSETS), ("coeffs_q", _p * MAX_TAPSETS),
+                ("default_mode", C.c_int32), ("mode", _p), ("tapset", _p), ("sqrt_kind", C.c_int32),
+                ("osc_len", C.c_uint32), ("osc_i", _p), ("osc_q", _p),
+                ("in_scale", C.c_float), ("num_biquad_stages", C.c_uint32), ("biquad_coeffs", _p),
+                ("num_biquad_nodes", C.c_uint32), ("node_stages", C.c_uint32 * 2), ("node_coefs", _p * 2),
+                ("time_segments", C.c_uint32), ("biquad_warmup", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class ChainInfo(C.Structure):
+    _fields_ = [("kernel", C.c_char * 64), ("grid", C.c_uint32), ("block", C.c_uint32), ("lds_bytes", C.c_uint32),
+                ("time_segments", C.c_uint32), ("warmup", C.c_uint32), ("tile", C.c_uint32),
+                ("taps_padded", C.c_uint32)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libmsdr.so (no GPU needed to load it or to use the host-side designers)."""
+    global _lib
+    if _lib is None:
+        path = path or os.environ.get("MSDR_LIB", LIB_PATH)
+        if not os.path.exists(path):
+            raise MsdrError(-100, "%s not built: run `make -C minimal-sdr_amd` (or __graft_entry__.build())" % path)
+        _lib = C.CDLL(path)
+        _lib.msdr_last_error.restype = C.c_char_p
+        _lib.msdr_version.restype = C.c_char_p
+        _lib.msdr_ctx_stream.restype = _p
+        _lib.msdr_calc_FIR_coeffs.restype = None
+        _lib.msdr_calc_FIR_coeffs.argtypes = [_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
+        _lib.msdr_biquad_design.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_double, _p]
+        _lib.msdr_malloc.argtypes = [_p, C.c_size_t, _p]
+        _lib.msdr_free.argtypes = [_p, _p]
+        _lib.msdr_memcpy_h2d.argtypes = [_p, _p, _p, C.c_size_t]
+        _lib.msdr_memcpy_d2h.argtypes = [_p, _p, _p, C.c_size_t]
+        _lib.msdr_memset.argtypes = [_p, _p, C.c_int, C.c_size_t]
+        _lib.msdr_ctx_create.argtypes = [C.c_int, _p, _p]
+        _lib.msdr_chain_process.argtypes = [_p, _p, _p, C.c_uint64]
+        _lib.msdr_chain_get_kernel_time.argtypes = [_p, _p, _p, C.c_int]
+        for n in ("msdr_fir_q15_process", "msdr_fir_f32_process", "msdr_biquad_df1_f32_process"):
+            getattr(_lib, n).argtypes = [_p, _p, _p, C.c_uint32]
+        _lib.msdr_biquad_q15_update.argtypes = [_p, _p, C.c_uint32]
+    return _lib
+
+
+def _ck(rc):
+    if rc != 0:
+        raise MsdrError(rc, load_library().msdr_last_error().decode())
+
+
+def _hp(a):
+    return a.ctypes.data_as(_p) if a is not None else None
+
+
+# ---- host-side designers (no device needed) ---------------------------------------------------
+def calc_fir_coeffs(n, fc, astop=70.0, ftype=0, dfc=0.0, fs=24000.0, room=None):
+    buf = np.zeros(room or (2 * n + 8), np.int16)
+    load_library().msdr_calc_FIR_coeffs(_hp(buf), int(n), float(fc), float(astop), int(ftype), float(dfc), float(fs))
+    return buf
+
+
+def biquad_design(kind, freq, q_or_gain, slope=1.0, fs=AUDIO_SAMPLE_RATE_EXACT):
+    c = np.zeros(5, np.int32)
+    _ck(load_library().msdr_biquad_design(int(kind), float(freq), float(q_or_gain), float(slope), float(fs), _hp(c)))
+    return c
+
+
+class DeviceArray:
+    """A typed device buffer owned through msdr_malloc/msdr_free."""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx, self.shape, self.dtype = ctx, tuple(np.atleast_1d(shape)), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        ptr = _p()
+        _ck(ctx.lib.msdr_malloc(ctx.h, self.nbytes, C.byref(ptr)))
+        self.ptr = ptr.value
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, self.dtype)
+        assert a.nbytes == self.nbytes, (a.shape, self.shape)
+        _ck(self.ctx.lib.msdr_memcpy_h2d(self.ctx.h, self.ptr, _hp(a), self.nbytes))
+        return self
+
+    def download(self):
+        out = np.empty(self.shape, self.dtype)
+        _ck(self.ctx.lib.msdr_memcpy_d2h(self.ctx.h, _hp(out), self.ptr, self.nbytes))
+        return out
+
+    def fill(self, byte):
+        _ck(self.ctx.lib.msdr_memset(self.ctx.h, self.ptr, int(byte), self.nbytes))
+        return self
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.msdr_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        h = _p()
+        _ck(self.lib.msdr_ctx_create(int(device), _p(stream) if stream else None, C.byref(h)))
+        self.h = h
+
+    def synchronize(self):
+        _ck(self.lib.msdr_ctx_synchronize(self.h))
+
+    def array(self, shape, dtype):
+        return DeviceArray(self, shape, dtype)
+
+    def to_device(self, a):
+        a = np.ascontiguousarray(a)
+        return DeviceArray(self, a.shape, a.dtype).upload(a)
+
+    # ---- stateless stages -----------------------------------------------------------------------
+    def mix_fs4_q15(self, d_x, d_i, d_q, channels, n):
+        _ck(self.lib.msdr_mix_fs4_q15(self.h, _p(d_x.ptr), _p(d_i.ptr), _p(d_q.ptr), C.c_uint32(channels), C.c_uint32(n)))
+
+    def freqconv_q15(self, d_i, d_q, osc_i, osc_q, direction, passthrough, channels, n):
+        oi, oq = np.ascontiguousarray(osc_i, np.int16), np.ascontiguousarray(osc_q, np.int16)
+        _ck(self.lib.msdr_freqconv_q15(self.h, _p(d_i.ptr), _p(d_q.ptr), _hp(oi), _hp(oq), C.c_uint32(oi.size),
+                                       int(direction), int(passthrough), C.c_uint32(channels), C.c_uint32(n)))
+
+    def freqconv_f32(self, d_i, d_q, osc_i, osc_q, direction, passthrough, channels, n):
+        oi, oq = np.ascontiguousarray(osc_i, np.float32), np.ascontiguousarray(osc_q, np.float32)
+        _ck(self.lib.msdr_freqconv_f32(self.h, _p(d_i.ptr), _p(d_q.ptr), _hp(oi), _hp(oq), C.c_uint32(oi.size),
+                                       int(direction), int(passthrough), C.c_uint32(channels), C.c_uint32(n)))
+
+    def demod_q15(self, mode, d_i, d_q, d_out, channels, n, sqrt_kind=SQRT_F32, d_mode=None):
+        _ck(self.lib.msdr_demod_q15(self.h, int(mode), _p(d_mode.ptr) if d_mode else None, int(sqrt_kind),
+                                    _p(d_i.ptr), _p(d_q.ptr), _p(d_out.ptr), C.c_uint32(channels), C.c_uint32(n)))
+
+    def demod_f32(self, mode, d_i, d_q, d_out, channels, n, d_mode=None):
+        _ck(self.lib.msdr_demod_f32(self.h, int(mode), _p(d_mode.ptr) if d_mode else None,
+                                    _p(d_i.ptr), _p(d_q.ptr), _p(d_out.ptr), C.c_uint32(channels), C.c_uint32(n)))
+
+    def close(self):
+        if self.h:
+            self.lib.msdr_ctx_destroy(self.h)
+            self.h = None
+
+
+class _Instance:
+    _destroy = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            getattr(self.ctx.lib, self._destroy)(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FirQ15(_Instance):
+    """arm_fir_init_q15 / arm_fir_fast_q15, batched over channels."""
+    _destroy = "msdr_fir_q15_destroy"
+
+    def __init__(self, ctx, coeffs, channels):
+        self.ctx = ctx
+        c = np.ascontiguousarray(coeffs, np.int16)
+        h = _p()
+        _ck(ctx.lib.msdr_fir_q15_create(ctx.h, C.c_uint16(c.size), _hp(c), C.c_uint32(channels), C.byref(h)))
+        self.h = h
+
+    def process(self, d_src, d_dst, n):
+        _ck(self.ctx.lib.msdr_fir_q15_process(self.h, d_src.ptr, d_dst.ptr, n))
+
+    def reset(self):
+        _ck(self.ctx.lib.msdr_fir_q15_reset(self.h))
+
+
+class FirF32(_Instance):
+    """arm_fir_init_f32 / arm_fir_f32, batched over channels."""
+    _destroy = "msdr_fir_f32_destroy"
+
+    def __init__(self, ctx, coeffs, channels):
+        self.ctx = ctx
+        c = np.ascontiguousarray(coeffs, np.float32)
+        h = _p()
+        _ck(ctx.lib.msdr_fir_f32_create(ctx.h, C.c_uint16(c.size), _hp(c), C.c_uint32(channels), C.byref(h)))
+        self.h = h
+
+    def process(self, d_src, d_dst, n):
+        _ck(self.ctx.lib.msdr_fir_f32_process(self.h, d_src.ptr, d_dst.ptr, n))
+
+    def reset(self):
+        _ck(self.ctx.lib.msdr_fir_f32_reset(self.h))
+
+
+class BiquadDf1F32(_Instance):
+    """arm_biquad_cascade_df1_init_f32 / arm_biquad_cascade_df1_f32, batched over channels."""
+    _destroy = "msdr_biquad_df1_f32_destroy"
+
+    def __init__(self, ctx, coeffs, channels):
+        self.ctx = ctx
+        c = np.ascontiguousarray(coeffs, np.float32).reshape(-1)
+        h = _p()
+        _ck(ctx.lib.msdr_biquad_df1_f32_create(ctx.h, C.c_uint8(c.size // 5), _hp(c) if c.size else None,
+                                               C.c_uint32(channels), C.byref(h)))
+        self.h = h
+
+    def process(self, d_src, d_dst, n):
+        _ck(self.ctx.lib.msdr_biquad_df1_f32_process(self.h, d_src.ptr, d_dst.ptr, n))
+
+    def reset(self):
+        _ck(self.ctx.lib.msdr_biquad_df1_f32_reset(self.h))
+
+
+class BiquadQ15(_Instance):
+    """AudioFilterBiquad: setCoefficients(stage, coef[5]) / update(), batched over channels."""
+    _destroy = "msdr_biquad_q15_destroy"
+
+    def __init__(self, ctx, channels):
+        self.ctx = ctx
+        h = _p()
+        _ck(ctx.lib.msdr_biquad_q15_create(ctx.h, C.c_uint32(channels), C.byref(h)))
+        self.h = h
+
+    def set_coefficients(self, stage, coef):
+        c = np.ascontiguousarray(coef, np.int32)
+        _ck(self.ctx.lib.msdr_biquad_q15_set_coefficients(self.h, C.c_uint32(stage), _hp(c)))
+
+    def update(self, d_data, n):
+        _ck(self.ctx.lib.msdr_biquad_q15_update(self.h, d_data.ptr, n))
+
+    def definition(self, channel=0):
+        d = np.zeros(32, np.int32)
+        _ck(self.ctx.lib.msdr_biquad_q15_get_definition(self.h, C.c_uint32(channel), _hp(d)))
+        return d
+
+
+class Chain(_Instance):
+    """The fused chain (msdr_chain_*): demodulation() + the biquad nodes behind it."""
+    _destroy = "msdr_chain_destroy"
+
+    def __init__(self, ctx, arith, channels, coeffs_i, coeffs_q, mixer=MIXER_FS4, mode=MODE_AM, modes=None,
+                 tapsets=None, osc_i=None, osc_q=None, sqrt_kind=SQRT_F32, in_scale=0.0, biquad_coeffs=None,
+                 biquad_nodes=(), time_segments=0, biquad_warmup=0, flags=0):
+        self.ctx, self.arith, self.channels = ctx, arith, channels
+        tdt = np.float32 if arith == ARITH_F32 else np.int16
+        ci = [np.ascontiguousarray(c, tdt) for c in (coeffs_i if isinstance(coeffs_i, (list, tuple)) else [coeffs_i])]
+        cq = [np.ascontiguousarray(c, tdt) for c in (coeffs_q if isinstance(coeffs_q, (list, tuple)) else [coeffs_q])]
+        keep = [ci, cq]
+        cfg = ChainConfig()
+        cfg.struct_size = C.sizeof(ChainConfig)
+        cfg.arith, cfg.channels, cfg.mixer = arith, channels, mixer
+        cfg.num_taps, cfg.num_tapsets = ci[0].size, len(ci)
+        for k in range(len(ci)):
+            cfg.coeffs_i[k], cfg.coeffs_q[k] = _hp(ci[k]), _hp(cq[k])
+        cfg.default_mode = mode
+        if modes is not None:
+            m = np.ascontiguousarray(modes, np.int32)
+            keep.append(m)
+            cfg.mode = _hp(m)
+        if tapsets is not None:
+            t = np.ascontiguousarray(tapsets, np.int32)
+            keep.append(t)
+            cfg.tapset = _hp(t)
+        cfg.sqrt_kind = sqrt_kind
+        if osc_i is not None:
+            oi, oq = np.ascontiguousarray(osc_i, tdt), np.ascontiguousarray(osc_q, tdt)
+            keep += [oi, oq]
+            cfg.osc_len, cfg.osc_i, cfg.osc_q = oi.size, _hp(oi), _hp(oq)
+        cfg.in_scale = in_scale
+        if biquad_coeffs is not None and arith == ARITH_F32:
+            b = np.ascontiguousarray(biquad_coeffs, np.float32).reshape(-1)
+            keep.append(b)
+            cfg.num_biquad_stages, cfg.biquad_coeffs = b.size // 5, _hp(b)
+        if arith == ARITH_Q15:
+            cfg.num_biquad_nodes = len(biquad_nodes)
+            for k, stages in enumerate(biquad_nodes):
+                s = np.ascontiguousarray(stages, np.int32).reshape(-1)
+                keep.append(s)
+                cfg.node_stages[k], cfg.node_coefs[k] = s.size // 5, _hp(s)
+        cfg.time_segments, cfg.biquad_warmup, cfg.flags = time_segments, biquad_warmup, flags
+        h = _p()
+        _ck(ctx.lib.msdr_chain_create(ctx.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def process(self, d_if, d_audio, n):
+        """d_if / d_audio: DeviceArray or raw device pointers (int)."""
+        pi = d_if.ptr if hasattr(d_if, "ptr") else int(d_if)
+        po = d_audio.ptr if hasattr(d_audio, "ptr") else int(d_audio)
+        _ck(self.ctx.lib.msdr_chain_process(self.h, pi, po, n))
+
+    def reset(self):
+        _ck(self.ctx.lib.msdr_chain_reset(self.h))
+
+    def set_mode(self, channel, mode, tapset=0):
+        _ck(self.ctx.lib.msdr_chain_set_mode(self.h, C.c_uint32(channel), C.c_int32(mode), C.c_int32(tapset)))
+
+    def info(self):
+        i = ChainInfo()
+        _ck(self.ctx.lib.msdr_chain_get_info(self.h, C.byref(i)))
+        return {"kernel": i.kernel.decode(), "grid": i.grid, "block": i.block, "lds_bytes": i.lds_bytes,
+                "time_segments": i.time_segments, "warmup": i.warmup, "tile": i.tile, "taps_padded": i.taps_padded}
+
+    def enable_timing(self, on=True):
+        _ck(self.ctx.lib.msdr_chain_enable_timing(self.h, int(on)))
+
+    def kernel_time(self, reset=True):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        _ck(self.ctx.lib.msdr_chain_get_kernel_time(self.h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value

@@ -1,0 +1,232 @@
+"""GPU parity of the fused chain (msdr_chain_*) through the C ABI.
+
+q15 arithmetic: bit-exact against the reference-generated golden vectors and the oracle.
+fp32 arithmetic: relative RMS <= 1e-5 per channel against the oracle's sequential fp32 chain
+(BASELINE.json north_star: "demodulated audio within 1e-5 RMS of the CMSIS reference")."""
+import numpy as np
+import pytest
+
+import orclib
+from gpuhelp import ctx, msdr, rel_rms  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+B = 128
+TOL = 1e-5
+CORR = orclib.AUDIO_SAMPLE_RATE_EXACT / 24000.0
+
+CHAIN = [("AM", orclib.AM, "fir/taps_am102", "fir/taps_am102"),
+         ("LSB", orclib.LSB, "taps/FIR_SSB_I_coeffs", "taps/FIR_SSB_Q_coeffs"),
+         ("USB", orclib.USB, "taps/FIR_SSB_I_coeffs", "taps/FIR_SSB_Q_coeffs"),
+         ("CW", orclib.CW, "taps/FIR_CW_I_coeffs", "taps/FIR_CW_Q_coeffs")]
+
+
+def run_chain(ctx, chain, x, out_dtype, block=None):
+    """x: [channels, n] int16. block=None -> one call; else consecutive calls of `block` samples."""
+    ch, n = x.shape
+    out = np.empty((ch, n), out_dtype)
+    step = block or n
+    for o in range(0, n, step):
+        m = min(step, n - o)
+        dx, dy = ctx.to_device(x[:, o:o + m]), ctx.array((ch, m), out_dtype)
+        chain.process(dx, dy, m)
+        out[:, o:o + m] = dy.download()
+    return out
+
+
+# ---------------------------------------------------------------- q15: golden --------------
+@pytest.mark.parametrize("mn,mode,ti,tq", CHAIN)
+@pytest.mark.parametrize("block", [128, None])
+def test_chain_q15_matches_reference_golden(ctx, golden, mn, mode, ti, tq, block):
+    sigs = ["am", "tones", "noise", "full"]
+    x = np.stack([golden["chain/x_" + s] for s in sigs])
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, len(sigs), golden[ti], golden[tq], mode=mode)
+    got = run_chain(ctx, chain, x, np.int16, block)
+    for c, s in enumerate(sigs):
+        assert np.array_equal(got[c], golden["chain/%s_%s_audio" % (s, mn)]), (s, mn, block)
+    if mn in ("AM", "CW"):
+        chain2 = msdr.Chain(ctx, msdr.ARITH_Q15, len(sigs), golden[ti], golden[tq], mode=mode, sqrt_kind=msdr.SQRT_Q31)
+        got = run_chain(ctx, chain2, x, np.int16, block)
+        for c, s in enumerate(sigs):
+            assert np.array_equal(got[c], golden["chain/%s_%s_audio_q31" % (s, mn)]), (s, mn)
+
+
+def _ref_nodes(orc):
+    lp = orc.biquad_design(orclib.BQ_LOWPASS, np.float32(6000 * 0.9 * CORR), 0.54)       # .ino:391-393
+    nt = orc.biquad_design(orclib.BQ_NOTCH, np.float32(24000 / 8 * CORR), 15.0)           # .ino:356
+    return lp, nt
+
+
+def test_chain_q15_reference_graph_mixed_modes(ctx, orc, golden):
+    """demodulation() + biquad1_dac (LP) + biquad2_dac (notch), per-channel mode and tap set (C5 shape)."""
+    lp, nt = _ref_nodes(orc)
+    rng = np.random.default_rng(30)
+    ch, n = 9, 24 * B
+    x = rng.integers(-12000, 12001, (ch, n)).astype(np.int16)
+    modes = np.array([orclib.AM, orclib.LSB, orclib.USB, orclib.CW, orclib.AM, orclib.LSB, orclib.USB, orclib.CW, orclib.AM], np.int32)
+    am = np.concatenate([golden["fir/taps_am102"]])                      # 102 taps
+    pad = lambda t: np.concatenate([np.zeros(102 - t.size, np.int16), t])   # front zero-padding = same filter
+    sets_i = [am, pad(golden["taps/FIR_SSB_I_coeffs"]), pad(golden["taps/FIR_CW_I_coeffs"])]
+    sets_q = [am, pad(golden["taps/FIR_SSB_Q_coeffs"]), pad(golden["taps/FIR_CW_Q_coeffs"])]
+    which = {orclib.AM: 0, orclib.LSB: 1, orclib.USB: 1, orclib.CW: 2}
+    tapsets = np.array([which[m] for m in modes], np.int32)
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, sets_i, sets_q, modes=modes, tapsets=tapsets, biquad_nodes=[[lp], [nt]])
+    for block in (128, 5 * B):
+        chain.reset()
+        nodes_fresh = msdr.Chain(ctx, msdr.ARITH_Q15, ch, sets_i, sets_q, modes=modes, tapsets=tapsets,
+                                 biquad_nodes=[[lp], [nt]])
+        got = run_chain(ctx, nodes_fresh, x, np.int16, block)
+        for c in range(ch):
+            want = orc.chain_q15(x[c], modes[c], sets_i[tapsets[c]], sets_q[tapsets[c]],
+                                 biquads=[orc.biquad_teensy_new([lp]), orc.biquad_teensy_new([nt])])
+            assert np.array_equal(got[c], want), (block, c)
+
+
+def test_chain_q15_nco_mixer_and_long_block(ctx, orc, golden):
+    """AudioEffectFreqConv front end (freq_conv.cpp) + a long block that the GPU splits in time."""
+    n = np.arange(B)
+    oi = np.round(32767 * np.sin(2 * np.pi * 32 * n / B)).astype(np.int16)
+    oq = np.round(32767 * np.cos(2 * np.pi * 32 * n / B)).astype(np.int16)
+    rng = np.random.default_rng(31)
+    x = rng.integers(-32768, 32768, (2, 400 * B)).astype(np.int16)
+    hi, hq = golden["taps/FIR_SSB_I_coeffs"], golden["taps/FIR_SSB_Q_coeffs"]
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, 2, hi, hq, mixer=msdr.MIXER_NCO, mode=orclib.LSB, osc_i=oi, osc_q=oq)
+    got = run_chain(ctx, chain, x, np.int16)
+    assert chain.info()["time_segments"] > 1
+    for c in range(2):
+        assert np.array_equal(got[c], orc.chain_q15(x[c], orclib.LSB, hi, hq, mixer=1, osc_i=oi, osc_q=oq))
+
+
+def test_chain_argument_errors(ctx, golden):
+    hi = golden["taps/FIR_SSB_I_coeffs"]
+    with pytest.raises(msdr.MsdrError) as e:
+        msdr.Chain(ctx, msdr.ARITH_Q15, 1, hi[:85], hi[:85])               # odd numTaps (arm_fir_init_q15.c:93-96)
+    assert e.value.status == msdr.STATUS_ARGUMENT_ERROR
+    with pytest.raises(msdr.MsdrError):
+        msdr.Chain(ctx, msdr.ARITH_F32, 1, hi.astype(np.float32), hi.astype(np.float32), mixer=msdr.MIXER_NCO)  # no tables
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, 1, hi, hi)
+    chain.process(0, 0, 0)                                                  # empty block: no-op
+    with pytest.raises(msdr.MsdrError):
+        chain.process(0, 0, 128)                                            # null buffers
+
+
+# ---------------------------------------------------------------- fp32 ---------------------
+def _hilbert_pair(n_taps, fc=1330.0, fs=24000.0, bw=1920.0):
+    """+-45 degree phase-added band-pass pair: Kaiser low-pass prototype modulated."""
+    k = np.arange(n_taps)
+    m = (n_taps - 1) / 2.0
+    proto = np.sinc(2 * (bw / 2) / fs * (k - m)) * np.kaiser(n_taps, 6.0)
+    proto /= proto.sum()
+    w = 2 * np.pi * fc / fs
+    hi = 2 * proto * np.cos(w * (k - m) + np.pi / 4)
+    hq = 2 * proto * np.cos(w * (k - m) - np.pi / 4)
+    return hi.astype(np.float32), hq.astype(np.float32)
+
+
+def _f32_biquads(orc, stages):
+    out = []
+    for k, q in enumerate([0.54, 15.0, 0.54, 1.3][:stages]):
+        kind = orclib.BQ_NOTCH if k == 1 else orclib.BQ_LOWPASS
+        c = orc.biquad_design(kind, np.float32((3000 if k == 1 else 5400) * CORR), q).astype(np.float64) / 2 ** 30
+        out.append([c[0], c[1], c[2], -c[3], -c[4]])
+    return np.array(out, np.float32).reshape(-1, 5)
+
+
+def _nco(p, cycles):
+    n = np.arange(p)
+    return np.sin(2 * np.pi * cycles * n / p).astype(np.float32), np.cos(2 * np.pi * cycles * n / p).astype(np.float32)
+
+
+@pytest.mark.parametrize("ntaps,mode,stages,block", [
+    (100, orclib.LSB, 2, None), (100, orclib.USB, 0, 128), (100, orclib.LSB, 2, 128),
+    (61, orclib.AM, 4, None), (256, orclib.AM, 1, None), (512, orclib.CW, 2, 1000), (7, orclib.LSB, 1, 333)])
+def test_chain_f32_nco_vs_oracle(ctx, orc, ntaps, mode, stages, block):
+    rng = np.random.default_rng(ntaps + stages)
+    hi, hq = _hilbert_pair(ntaps)
+    oi, oq = _nco(128, 32)
+    bq = _f32_biquads(orc, stages)
+    x = rng.integers(-8000, 8001, (3, 6000)).astype(np.int16)
+    x[1] = np.round(6000 * np.cos(2 * np.pi * 6700 * np.arange(6000) / 24000)).astype(np.int16)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 3, hi, hq, mixer=msdr.MIXER_NCO, mode=mode, osc_i=oi, osc_q=oq,
+                       biquad_coeffs=bq if stages else None)
+    got = run_chain(ctx, chain, x, np.float32, block)
+    for c in range(3):
+        want = orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq if stages else None)
+        assert rel_rms(got[c], want) < TOL, (c, rel_rms(got[c], want))
+
+
+@pytest.mark.parametrize("mode", [orclib.AM, orclib.LSB, orclib.USB])
+def test_chain_f32_fs4_vs_oracle_and_q15(ctx, orc, golden, mode):
+    """Fs/4 mixer in fp32 with the reference's own (Q15-scaled) tap sets: matches the fp32 oracle
+    to 1e-5 and tracks the bit-exact q15 golden audio within the q15 truncation bound."""
+    ti, tq = ("fir/taps_am102", "fir/taps_am102") if mode == orclib.AM else ("taps/FIR_SSB_I_coeffs", "taps/FIR_SSB_Q_coeffs")
+    hi, hq = golden[ti].astype(np.float32) / 32768, golden[tq].astype(np.float32) / 32768
+    sigs = ["am", "tones", "noise"]
+    x = np.stack([golden["chain/x_" + s] for s in sigs])
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 3, hi, hq, mixer=msdr.MIXER_FS4, mode=mode, in_scale=1.0)
+    got = run_chain(ctx, chain, x, np.float32, 128)
+    cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+    mn = {orclib.AM: "AM", orclib.LSB: "LSB", orclib.USB: "USB"}[mode]
+    for c, s in enumerate(sigs):
+        want = orc.chain_f32(x[c], mode, hi, hq, sin4, cos4, None, in_scale=1.0)
+        assert rel_rms(got[c], want) < TOL
+        assert np.abs(got[c] - golden["chain/%s_%s_audio" % (s, mn)]).max() <= 3.0
+
+
+def test_chain_f32_time_segments_vs_sequential(ctx, orc):
+    """One channel, one long block: the GPU splits it into time segments and re-converges the IIR
+    over a warm-up; result must stay within 1e-5 of the strictly sequential oracle, also right at
+    the segment boundaries."""
+    rng = np.random.default_rng(40)
+    n = 1 << 20
+    x = rng.integers(-8000, 8001, (1, n)).astype(np.int16)
+    hi, hq = _hilbert_pair(100)
+    oi, oq = _nco(128, 32)
+    bq = _f32_biquads(orc, 2)                                   # LP + the Q=15 notch (slowest-decaying pole pair)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 1, hi, hq, mixer=msdr.MIXER_NCO, mode=orclib.LSB, osc_i=oi, osc_q=oq,
+                       biquad_coeffs=bq)
+    got = run_chain(ctx, chain, x, np.float32)
+    info = chain.info()
+    assert info["time_segments"] > 1 and info["warmup"] > 0
+    want = orc.chain_f32(x[0], orclib.LSB, hi, hq, oi, oq, bq)
+    assert rel_rms(got[0], want) < TOL
+    seg = -(-n // info["time_segments"])
+    seg = -(-seg // info["tile"]) * info["tile"]
+    for s in range(1, info["time_segments"]):
+        lo = s * seg
+        if lo + 64 <= n:
+            assert rel_rms(got[0, lo:lo + 64], want[lo:lo + 64]) < TOL, s
+    # forcing exact state carry (time_segments=1) agrees as well, and so does a second call (state carried)
+    chain1 = msdr.Chain(ctx, msdr.ARITH_F32, 1, hi, hq, mixer=msdr.MIXER_NCO, mode=orclib.LSB, osc_i=oi, osc_q=oq,
+                        biquad_coeffs=bq, time_segments=1)
+    got1 = run_chain(ctx, chain1, x[:, :200000], np.float32)
+    assert chain1.info()["time_segments"] == 1
+    assert rel_rms(got1[0], want[:200000]) < TOL
+
+
+def test_chain_f32_mixed_modes_many_channels(ctx, orc):
+    """C5 shape in small: per-channel AM/LSB select with per-mode tap sets, 512 taps, int16 in / fp32 out."""
+    rng = np.random.default_rng(41)
+    ch, n = 40, 5000
+    lp = np.zeros(512, np.float32)
+    lp[:] = (np.sinc(2 * 2800 / 24000 * (np.arange(512) - 255.5)) * np.kaiser(512, 7.0)).astype(np.float32)
+    lp /= lp.sum()
+    hi, hq = _hilbert_pair(512)
+    modes = np.array([orclib.AM if (c * 2654435761) & 1 else orclib.LSB for c in range(ch)], np.int32)
+    tapsets = np.array([0 if m == orclib.AM else 1 for m in modes], np.int32)
+    x = rng.integers(-8000, 8001, (ch, n)).astype(np.int16)
+    bq = _f32_biquads(orc, 1)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, [lp, hi], [lp, hq], mixer=msdr.MIXER_FS4, modes=modes, tapsets=tapsets,
+                       biquad_coeffs=bq)
+    got = run_chain(ctx, chain, x, np.float32)
+    cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+    for c in range(ch):
+        ti, tq = ([lp, hi][tapsets[c]], [lp, hq][tapsets[c]])
+        want = orc.chain_f32(x[c], modes[c], ti, tq, sin4, cos4, bq)
+        assert rel_rms(got[c], want) < TOL, c
+    # retune one channel (msdr_chain_set_mode) and check it alone changes
+    chain.reset()
+    chain.set_mode(3, orclib.USB, 1)
+    got2 = run_chain(ctx, chain, x, np.float32)
+    want3 = orc.chain_f32(x[3], orclib.USB, hi, hq, sin4, cos4, bq)
+    assert rel_rms(got2[3], want3) < TOL
+    assert np.array_equal(got2[5], got[5])

@@ -1,0 +1,213 @@
+"""GPU parity of the kernel-function API (CMSIS / Teensy-Audio mirrors) against the oracle and the
+reference-generated golden vectors.  Everything goes through the C ABI (include/msdr.h).
+Integer paths: bit-exact.  fp32 paths: relative RMS <= 1e-5 per channel (north-star tolerance);
+most are far tighter and the tighter bound is what is asserted."""
+import numpy as np
+import pytest
+
+import orclib
+from gpuhelp import ctx, msdr, rel_rms  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+B = 128
+
+
+def _rand16(rng, shape, amp=32767):
+    return rng.integers(-amp - 1 if amp == 32767 else -amp, amp + 1, shape).astype(np.int16)
+
+
+# ---------------------------------------------------------------- A1 / A2 / A5 -------------
+def test_mix_fs4_q15(ctx, orc):
+    rng = np.random.default_rng(1)
+    x = _rand16(rng, (5, 4 * B))
+    x[0, :8] = -32768
+    dx = ctx.to_device(x)
+    di, dq = ctx.array(x.shape, np.int16), ctx.array(x.shape, np.int16)
+    ctx.mix_fs4_q15(dx, di, dq, x.shape[0], x.shape[1])
+    gi, gq = di.download(), dq.download()
+    for c in range(x.shape[0]):
+        wi, wq = orc.mix_fs4(x[c])
+        assert np.array_equal(gi[c], wi) and np.array_equal(gq[c], wq)
+
+
+@pytest.mark.parametrize("direction", [0, 1])
+@pytest.mark.parametrize("passthrough", [0, 1])
+def test_freqconv(ctx, orc, direction, passthrough):
+    rng = np.random.default_rng(2 + direction)
+    i, q = _rand16(rng, (3, B)), _rand16(rng, (3, B))
+    n = np.arange(B)
+    oi = np.round(32767 * np.sin(2 * np.pi * 5 * n / B)).astype(np.int16)
+    oq = np.round(32767 * np.cos(2 * np.pi * 5 * n / B)).astype(np.int16)
+    oi[3], oq[3], i[:, 3], q[:, 3] = -32768, -32768, -32768, -32768
+    di, dq = ctx.to_device(i), ctx.to_device(q)
+    ctx.freqconv_q15(di, dq, oi, oq, direction, passthrough, 3, B)
+    gi, gq = di.download(), dq.download()
+    for c in range(3):
+        wi, wq = orc.freqconv_q15(i[c], q[c], oi, oq, direction, passthrough)
+        assert np.array_equal(gi[c], wi) and np.array_equal(gq[c], wq)
+    fi, fq = (i / 32768).astype(np.float32), (q / 32768).astype(np.float32)
+    foi, foq = (oi / 32768).astype(np.float32), (oq / 32768).astype(np.float32)
+    di, dq = ctx.to_device(fi), ctx.to_device(fq)
+    ctx.freqconv_f32(di, dq, foi, foq, direction, passthrough, 3, B)
+    gi, gq = di.download(), dq.download()
+    for c in range(3):
+        wi, wq = orc.freqconv_f32(fi[c], fq[c], foi, foq, direction, passthrough)
+        assert np.allclose(gi[c], wi, rtol=0, atol=2e-7) and np.allclose(gq[c], wq, rtol=0, atol=2e-7)
+
+
+def test_demod_q15_all_modes(ctx, orc):
+    rng = np.random.default_rng(3)
+    i, q = _rand16(rng, (5, 2 * B)), _rand16(rng, (5, 2 * B))
+    i[:, :4], q[:, :4] = -32768, -32768          # int32 overflow of I*I+Q*Q
+    i[:, 4:8], q[:, 4:8] = 32767, 32767          # sqrt > 32767: truncating store wraps
+    modes = np.array([orclib.AM, orclib.LSB, orclib.USB, orclib.CW, orclib.SYNCAM], np.int32)
+    di, dq, do = ctx.to_device(i), ctx.to_device(q), ctx.array(i.shape, np.int16)
+    dm = ctx.to_device(modes)
+    for kind in (orclib.SQRT_F32, orclib.SQRT_Q31):
+        ctx.demod_q15(orclib.AM, di, dq, do, 5, 2 * B, sqrt_kind=kind, d_mode=dm)
+        got = do.download()
+        for c in range(5):
+            assert np.array_equal(got[c], orc.demod_q15(modes[c], i[c], q[c], kind)), (kind, c)
+    ctx.demod_q15(orclib.USB, di, dq, do, 5, 2 * B)
+    assert np.array_equal(do.download()[1], orc.demod_q15(orclib.USB, i[1], q[1]))
+
+
+def test_demod_q15_sqrt_exhaustive_boundaries(ctx, orc):
+    """trunc(sqrtf(float(s))) must agree with the CPU for sums right below/at perfect squares."""
+    k = np.arange(1, 32767, dtype=np.int64)
+    i = np.concatenate([k, k, k]).astype(np.int16)
+    q = np.zeros_like(i)
+    # s = k*k exactly; plus pairs whose sum is k*k - 1 or k*k + 1 are covered by random draws below
+    rng = np.random.default_rng(4)
+    i2, q2 = _rand16(rng, i.size, 23000), _rand16(rng, i.size, 23000)
+    I, Q = np.concatenate([i, i2]), np.concatenate([q, q2])
+    di, dq, do = ctx.to_device(I[None]), ctx.to_device(Q[None]), ctx.array((1, I.size), np.int16)
+    ctx.demod_q15(orclib.AM, di, dq, do, 1, I.size)
+    assert np.array_equal(do.download()[0], orc.demod_q15(orclib.AM, I, Q))
+
+
+def test_demod_f32(ctx, orc):
+    rng = np.random.default_rng(5)
+    i, q = rng.standard_normal((4, B)).astype(np.float32), rng.standard_normal((4, B)).astype(np.float32)
+    modes = np.array([orclib.AM, orclib.LSB, orclib.USB, orclib.CW], np.int32)
+    di, dq, do, dm = ctx.to_device(i), ctx.to_device(q), ctx.array(i.shape, np.float32), ctx.to_device(modes)
+    ctx.demod_f32(orclib.AM, di, dq, do, 4, B, d_mode=dm)
+    got = do.download()
+    for c in range(4):
+        assert np.allclose(got[c], orc.demod_f32(modes[c], i[c], q[c]), rtol=3e-7, atol=0)
+
+
+# ---------------------------------------------------------------- A3 / A4 q15 FIR ----------
+@pytest.mark.parametrize("tn", ["ssb_i", "am102", "lp256", "lp512", "lp62", "wrap8", "n4", "n6"])
+def test_fir_q15_vs_reference_golden(ctx, golden, tn):
+    taps = golden["fir/taps_" + tn]
+    fir = msdr.FirQ15(ctx, taps, 2)
+    for sn in ("noise", "full"):
+        x = golden["fir/x_" + sn]
+        xx = np.stack([x, x[::-1].copy()])
+        for blk in (128, 130, 7):
+            fir.reset()
+            got = np.empty_like(xx)
+            for o in range(0, x.size, blk):
+                n = min(blk, x.size - o)
+                dx, dy = ctx.to_device(xx[:, o:o + n]), ctx.array((2, n), np.int16)
+                fir.process(dx, dy, n)
+                got[:, o:o + n] = dy.download()
+            assert np.array_equal(got[0], golden["fir/%s_%s_b%d" % (tn, sn, blk)]), (tn, sn, blk)
+    fir.close()
+
+
+def test_fir_q15_rejects_odd_taps_and_inplace(ctx):
+    with pytest.raises(msdr.MsdrError) as e:
+        msdr.FirQ15(ctx, np.ones(5, np.int16), 1)
+    assert e.value.status == msdr.STATUS_ARGUMENT_ERROR        # arm_fir_init_q15.c:93-96
+    fir = msdr.FirQ15(ctx, np.ones(4, np.int16), 1)
+    d = ctx.to_device(np.zeros((1, B), np.int16))
+    with pytest.raises(msdr.MsdrError):
+        fir.process(d, d, B)
+
+
+def test_fir_q15_long_block_time_segments(ctx, orc):
+    """One long block is split into time segments on the GPU; the integer result is still exact."""
+    rng = np.random.default_rng(6)
+    taps = _rand16(rng, 102, 3000)
+    x = _rand16(rng, (3, 100003))
+    fir = msdr.FirQ15(ctx, taps, 3)
+    dx, dy = ctx.to_device(x), ctx.array(x.shape, np.int16)
+    fir.process(dx, dy, x.shape[1])
+    got = dy.download()
+    for c in range(3):
+        _, want = orc.fir_q15_blocks(taps, x[c], x.shape[1])
+        assert np.array_equal(got[c], want)
+
+
+# ---------------------------------------------------------------- A6 fp32 FIR --------------
+@pytest.mark.parametrize("ntaps", [1, 3, 61, 100, 256, 512])
+def test_fir_f32_vs_oracle(ctx, orc, ntaps):
+    rng = np.random.default_rng(ntaps)
+    h = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    x = rng.uniform(-1, 1, (3, 7001)).astype(np.float32)
+    fir = msdr.FirF32(ctx, h, 3)
+    got = np.empty_like(x)
+    for o, n in ((0, 4000), (4000, 3001)):                       # state carried between two calls
+        dx, dy = ctx.to_device(x[:, o:o + n]), ctx.array((3, n), np.float32)
+        fir.process(dx, dy, n)
+        got[:, o:o + n] = dy.download()
+    for c in range(3):
+        assert rel_rms(got[c], orc.fir_f32_blocks(h, x[c], 128)) < 1e-6
+
+
+# ---------------------------------------------------------------- A8 fp32 biquad -----------
+@pytest.mark.parametrize("stages", [0, 1, 2, 4])
+def test_biquad_df1_f32_vs_oracle(ctx, orc, stages):
+    rng = np.random.default_rng(10 + stages)
+    corr = orclib.AUDIO_SAMPLE_RATE_EXACT / 24000.0
+    coeffs = []
+    for k, q in enumerate([0.54, 15.0, 0.54, 1.3][:stages]):
+        kind = orclib.BQ_NOTCH if k == 1 else orclib.BQ_LOWPASS
+        c = orc.biquad_design(kind, np.float32((3000 if k == 1 else 5400) * corr), q).astype(np.float64) / 2 ** 30
+        coeffs.append([c[0], c[1], c[2], -c[3], -c[4]])
+    coeffs = np.array(coeffs, np.float32).reshape(-1, 5)
+    x = rng.uniform(-1, 1, (3, 9000)).astype(np.float32)
+    bq = msdr.BiquadDf1F32(ctx, coeffs, 3)
+    got = np.empty_like(x)
+    for o, n in ((0, 128), (128, 5000), (5128, 3872)):
+        dx, dy = ctx.to_device(x[:, o:o + n]), ctx.array((3, n), np.float32)
+        bq.process(dx, dy, n)
+        got[:, o:o + n] = dy.download()
+    for c in range(3):
+        assert rel_rms(got[c], orc.biquad_df1_blocks(coeffs, x[c], 128)) < 2e-6
+
+
+# ---------------------------------------------------------------- A7 Teensy biquad ---------
+@pytest.mark.parametrize("n_stage", [1, 2, 4])
+def test_biquad_q15_bit_exact(ctx, orc, n_stage):
+    rng = np.random.default_rng(20 + n_stage)
+    corr = orclib.AUDIO_SAMPLE_RATE_EXACT / 24000.0
+    coefs = [orc.biquad_design(orclib.BQ_LOWPASS, np.float32(5400 * corr), q) for q in [0.54, 1.3, 0.54, 1.3][:n_stage]]
+    ch = 70                                                       # more than one 64-channel workgroup
+    node = msdr.BiquadQ15(ctx, ch)
+    for s, c in enumerate(coefs):
+        node.set_coefficients(s, c)
+    node.set_coefficients(4, coefs[0])                            # ignored (filter_biquad.cpp:86)
+    refs = [orc.biquad_teensy_new(coefs) for _ in range(ch)]
+    assert list(node.definition(0)) == list(refs[0].definition)
+    for blk in range(5):
+        amp = 32767 if blk in (2, 3) else 4000
+        x = _rand16(rng, (ch, 2 * B), amp)
+        if blk == 2:
+            x[:, :] = 32767                                       # drive into saturation
+        d = ctx.to_device(x)
+        node.update(d, 2 * B)
+        got = d.download()
+        for c in range(ch):
+            assert np.array_equal(got[c], orc.biquad_teensy_update(refs[c], x[c])), (blk, c)
+    assert list(node.definition(ch - 1)) == list(refs[ch - 1].definition)
+    # re-tuning keeps the history words, clears the residue (filter_biquad.cpp:95-98)
+    node.set_coefficients(0, coefs[-1])
+    orc.lib.orc_biquad_teensy_set_coefficients(orclib.C.byref(refs[3]), 0, coefs[-1].ctypes.data_as(orclib._p))
+    assert list(node.definition(3)) == list(refs[3].definition)
+    d = ctx.to_device(np.zeros((ch, 7), np.int16))
+    with pytest.raises(msdr.MsdrError) as e:
+        node.update(d, 7)
+    assert e.value.status == msdr.STATUS_LENGTH_ERROR

@@ -124,7 +124,7 @@ def cpu_baseline(wl, x_host, gpu_first, target_s=12.0):
         used = 1
         for s in sorted(set(ts.tolist())):
             idx = np.nonzero(ts == s)[0]
-            o, used = orc.chain_f32_batch(xs[idx], modes[idx], wl["ci"][s], wl["cq"][s], osc_i, osc_q, wl["bq"], threads=thr)
+            o, used = orc.chain_f32_batch(xs[idx], modes[idx], wl["ci"][s], wl["cq"][s], osc_i, osc_q, wl["bq"] if len(wl["bq"]) else None, threads=thr)
             outs[idx] = o
         return outs, time.perf_counter() - t0, used
 
@@ -169,6 +169,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-fold", action="store_true", help="keep mixer and FIR as separate arithmetic steps")
     ap.add_argument("--time-segments", type=int, default=0)
+    ap.add_argument("--stages", type=int, default=-1, help="experiment: override the number of biquad stages (0..2)")
+    ap.add_argument("--taps", type=int, default=0, help="experiment: override the tap count (same designer)")
     args = ap.parse_args()
 
     import torch
@@ -196,16 +198,34 @@ def main():
         wl["channels"] = args.channels
         if wl["modes"] is not None:
             wl["modes"], wl["tapsets"] = np.resize(wl["modes"], args.channels), np.resize(wl["tapsets"], args.channels)
+    if args.stages >= 0:
+        wl["bq"] = wl["bq"][:args.stages]
+        wl["name"] += " [experiment: %d biquad stages]" % args.stages
+    if args.taps:
+        pair = len(wl["ci"]) == 1 and wl["mode"] == msdr.MODE_LSB
+        if pair:
+            hi, hq = hilbert_pair(args.taps)
+            wl["ci"], wl["cq"] = [hi], [hq]
+        else:
+            lp = lowpass(args.taps)
+            hi, hq = hilbert_pair(args.taps)
+            wl["ci"], wl["cq"] = ([lp], [lp]) if len(wl["ci"]) == 1 else ([lp, hi], [lp, hq])
+        wl["taps"] = args.taps
+        wl["name"] += " [experiment: %d taps]" % args.taps
     ch, n = wl["channels"], wl["n"]
 
-    stream = torch.cuda.current_stream(dev)
+    # One explicit HIP stream shared by torch (input synthesis, events, RCCL ordering) and the library.
+    # (torch's default stream is the NULL stream, which msdr_ctx_create reads as "create your own".)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     ctx = msdr.Context(local_rank, stream.cuda_stream)
     chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, wl["ci"], wl["cq"], mixer=wl["mixer"], mode=wl["mode"], modes=wl["modes"],
                        tapsets=wl["tapsets"], osc_i=wl["osc"][0] if wl["osc"] else None, osc_q=wl["osc"][1] if wl["osc"] else None,
-                       biquad_coeffs=wl["bq"], time_segments=args.time_segments,
+                       biquad_coeffs=wl["bq"] if len(wl["bq"]) else None, time_segments=args.time_segments,
                        flags=msdr.CHAIN_NO_TAP_FOLDING if args.no_fold else 0)
     x = synth_if(torch, dev, ch, n, wl["seed"])
     y = torch.empty((ch, n), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
 
     def barrier():
         torch.cuda.synchronize(dev)

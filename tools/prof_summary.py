@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile.sh output directory: per-kernel time (rocprofv3 --stats) and per-launch HBM
+traffic of the chain kernel from the FETCH_SIZE / WRITE_SIZE counter passes, corrected as
+/opt/skills/guides prescribe: counters are in KiB (x1024), and on gfx950 FETCH_SIZE reports half of the
+bytes of a wide (16 B/lane) coalesced streaming read (x2)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+out, args = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else ""
+print("command: python3 bench.py", args)
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    print("\n== kernel stats (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, out))
+    rows = list(csv.DictReader(open(f)))
+    for r in rows[:12]:
+        print("  %-70s calls %6s  total %12s ns  avg %12s ns  %5s %%" % (r.get("Name", "")[:70], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
+line = [l for l in open(os.path.join(out, "trace.log")) if l.startswith("{")]
+if line:
+    j = json.loads(line[-1])
+    print("\nbench line under the profiler: value %.1f %s, kernel_ms %.4f, achieved %.1f GB/s (frac %.4f)" % (
+        j["value"], j["unit"], j["roofline"]["kernel_ms"], j["roofline"]["achieved"], j["roofline"]["frac"]))
+    alg = 6.0 * j["config"]["channels_per_gpu"] * j["config"]["samples_per_channel_per_step"]
+    print("algorithmic bytes per launch: %.0f (2 B in + 4 B out per sample)" % alg)
+res = {}
+for name in ("fetch", "write"):
+    tot, cnt = 0.0, 0
+    for f in glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "chain_kernel" in r.get("Kernel_Name", ""):
+                tot += float(r.get("Counter_Value", 0)); cnt += 1
+    res[name] = (tot, cnt)
+    print("%s counter: %d chain_kernel dispatches, mean raw value %.1f" % (name.upper() + "_SIZE", cnt, tot / cnt if cnt else float("nan")))
+if res["fetch"][1] and res["write"][1]:
+    fb = res["fetch"][0] / res["fetch"][1] * 1024 * 2      # KiB -> B, gfx950 wide-read correction x2
+    wb = res["write"][0] / res["write"][1] * 1024
+    print("HBM traffic per chain_kernel launch: read %.0f B (FETCH_SIZE x1024 x2), write %.0f B (WRITE_SIZE x1024), total %.0f B" % (fb, wb, fb + wb))
+    if line:
+        print("traffic / algorithmic = %.3f" % ((fb + wb) / alg))

@@ -55,10 +55,12 @@ def reference_biquads(msdr):
     return np.array(out, np.float32)
 
 
-def workload(name, msdr, rank):
+def workload(name, msdr, rank, osc_period=4):
+    # freq_conv-style oscillator: the reference's tables are q15 (Osc_I/Q_buffer_i, freq_conv.h:33-34), one
+    # AUDIO_BLOCK long, here at fs/4; converted to float as arm_q15_to_float does (/32768)
     osc_n = np.arange(128)
-    osc_i = np.sin(2 * np.pi * 32 * osc_n / 128).astype(np.float32)      # Osc_I_buffer_i ("sin"), fs/4
-    osc_q = np.cos(2 * np.pi * 32 * osc_n / 128).astype(np.float32)
+    osc_i = (np.round(32767 * np.sin(2 * np.pi * osc_n / osc_period)).astype(np.int16) / 32768.0).astype(np.float32)
+    osc_q = (np.round(32767 * np.cos(2 * np.pi * osc_n / osc_period)).astype(np.int16) / 32768.0).astype(np.float32)
     bq = reference_biquads(msdr)
     if name == "c2":
         hi, hq = hilbert_pair(100)
@@ -169,6 +171,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-fold", action="store_true", help="keep mixer and FIR as separate arithmetic steps")
     ap.add_argument("--time-segments", type=int, default=0)
+    ap.add_argument("--osc-period", type=int, default=4, help="experiment: NCO period in samples (4 = fs/4, the named config)")
     ap.add_argument("--stages", type=int, default=-1, help="experiment: override the number of biquad stages (0..2)")
     ap.add_argument("--taps", type=int, default=0, help="experiment: override the tap count (same designer)")
     args = ap.parse_args()
@@ -191,7 +194,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    wl = workload(args.workload, msdr, rank)
+    wl = workload(args.workload, msdr, rank, args.osc_period)
     if args.samples:
         wl["n"] = args.samples
     if args.channels:

@@ -4,6 +4,7 @@
 // process/update entry point launches HIP kernels or fails.
 #include "../../include/msdr.h"
 #include "msdr_kernels.hiph"
+#include "msdr_chain_fold.hiph"
 #include "msdr_design.h"
 
 #include <algorithm>
@@ -575,6 +576,13 @@ struct msdr_chain {
     long long phase;                  // absolute sample index modulo the NCO period
     BiquadStageTables<kChainR> *d_bq;
     float *d_bq_state;
+    // folded F32 path (msdr_chain_fold.hiph)
+    int fold_P;                       // 0 = not foldable; else NCO period 1, 2 or 4
+    bool fold_fs4_exact;              // oscillator is exactly {1,0,-1,0}/{0,1,0,-1}: AM can be folded too
+    float *d_ftaps;                   // [tapsets*3][P rotations][steps][PE rows][2 pair-columns][2]
+    int *d_fset;                      // [channels]
+    BiquadStageTables<kFoldR> *d_bq_fold;
+    std::vector<int> h_mode, h_tapset;
     msdr_biquad_q15 *nodes[2];
     msdr_chain_info info;
     // optional per-launch timing of the main kernel
@@ -589,6 +597,7 @@ static void chain_free(msdr_chain *c)
     if (!c) return;
     hipFree(c->d_taps); hipFree(c->d_osc); hipFree(c->d_mode); hipFree(c->d_tapset);
     hipFree(c->d_hist[0]); hipFree(c->d_hist[1]); hipFree(c->d_bq); hipFree(c->d_bq_state);
+    hipFree(c->d_ftaps); hipFree(c->d_fset); hipFree(c->d_bq_fold);
     for (int k = 0; k < 2; k++) if (c->nodes[k]) msdr_biquad_q15_destroy(c->nodes[k]);
     for (auto &e : c->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete c;
@@ -678,6 +687,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         }
         if (!rc) rc = upload(ctx, m, &c->d_mode);
         if (!rc) rc = upload(ctx, ts, &c->d_tapset);
+        c->h_mode = m; c->h_tapset = ts;
     }
     if (!rc) rc = dzalloc(ctx, (size_t)c->channels * c->hist_len, &c->d_hist[0]);
     if (!rc) rc = dzalloc(ctx, (size_t)c->channels * c->hist_len, &c->d_hist[1]);
@@ -686,6 +696,71 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         for (uint32_t s = 0; s < c->nstages; s++) make_stage_tables<kChainR>(cfg->biquad_coeffs + 5 * s, &tabs[s]);
         rc = upload(ctx, tabs, &c->d_bq);
         if (!rc) rc = dzalloc(ctx, (size_t)c->channels * kMaxStages * 4, &c->d_bq_state);
+    }
+    // ---- tap folding (F32): oscillator period, folded tables, per-channel folded-set index ----------
+    c->fold_P = 0; c->fold_fs4_exact = false;
+    if (!rc && f32 && !(cfg->flags & MSDR_CHAIN_NO_TAP_FOLDING)) {
+        std::vector<double> oc, os;                       // one period of cos / sin
+        if (cfg->mixer == MSDR_MIXER_FS4) { oc = {1, 0, -1, 0}; os = {0, 1, 0, -1}; }
+        else {
+            const float *fq = (const float *)cfg->osc_q, *fi = (const float *)cfg->osc_i;
+            for (uint32_t P : {1u, 2u, 4u}) {
+                if (cfg->osc_len % P) continue;
+                bool periodic = true;
+                for (uint32_t k = P; k < cfg->osc_len && periodic; k++) periodic = (fq[k] == fq[k - P]) && (fi[k] == fi[k - P]);
+                if (periodic) { oc.assign(fq, fq + P); os.assign(fi, fi + P); break; }
+            }
+        }
+        if (!oc.empty()) {
+            const int P = (int)oc.size();
+            c->fold_P = P;
+            c->fold_fs4_exact = (P == 4 && oc[0] == 1 && oc[1] == 0 && oc[2] == -1 && oc[3] == 0 &&
+                                 os[0] == 0 && os[1] == 1 && os[2] == 0 && os[3] == -1);
+            // T_phi[k] = in_scale * (hI[k] c[psi] -/+ hQ[k] s[psi]),  psi = (phi - (Np-1) + k) mod P  (k = padded tap index).
+            // Stored once per starting phase `rot` as [set*3+v][rot][step][row j < PE][pair-column i < 2][2]:
+            // row j serves outputs r = j (mod PE) whose phase is phi = (rot + j) mod P; pair-column m = 2*step + i holds
+            // (T[2m-1], T[2m]) for even rows and (T[2m], T[2m+1]) for odd rows (T = 0 outside [0, Np)).
+            const int PE = P < 2 ? 2 : P;
+            const int steps = fold_steps((int)np);
+            std::vector<float> ft((size_t)c->tapsets * 3 * P * steps * 4 * PE, 0.0f);
+            std::vector<double> T(np + 2);
+            for (uint32_t s = 0; s < c->tapsets; s++)
+                for (int v = 0; v < 3; v++)
+                    for (int rot = 0; rot < P; rot++)
+                        for (int j = 0; j < PE; j++) {
+                            const int phi = (rot + j) % P;
+                            std::fill(T.begin(), T.end(), 0.0);
+                            for (uint32_t k = 0; k < c->ntaps; k++) {
+                                const uint32_t kp = off + k;
+                                const int psi = (int)((((long long)phi - (long long)(np - 1) + kp) % P + P) % P);
+                                const double hi = ((const float *)cfg->coeffs_i[s])[k], hq = ((const float *)cfg->coeffs_q[s])[k];
+                                T[kp] = (hi * oc[psi] + (v == 0 ? -1.0 : 1.0) * hq * os[psi]) * (double)c->in_scale;
+                            }
+                            auto tap = [&](long long k) { return (k >= 0 && k < (long long)np) ? (float)T[k] : 0.0f; };
+                            float *base = ft.data() + (((size_t)s * 3 + v) * P + rot) * ((size_t)steps * 4 * PE);
+                            for (int st = 0; st < steps; st++)
+                                for (int i = 0; i < 2; i++) {
+                                    const long long m = 2LL * st + i;
+                                    const long long k0 = (j & 1) ? 2 * m : 2 * m - 1;
+                                    base[((size_t)st * PE + j) * 4 + 2 * i + 0] = tap(k0);
+                                    base[((size_t)st * PE + j) * 4 + 2 * i + 1] = tap(k0 + 1);
+                                }
+                        }
+            rc = upload(ctx, ft, &c->d_ftaps);
+            if (!rc) {
+                std::vector<BiquadStageTables<kFoldR>> tabs(std::max<uint32_t>(c->nstages, 1));
+                for (uint32_t s = 0; s < c->nstages; s++) make_stage_tables<kFoldR>(cfg->biquad_coeffs + 5 * s, &tabs[s]);
+                rc = upload(ctx, tabs, &c->d_bq_fold);
+            }
+            if (!rc) {
+                std::vector<int> fs(c->channels);
+                for (uint32_t ch = 0; ch < c->channels; ch++) {
+                    const int m = c->h_mode[ch];
+                    fs[ch] = c->h_tapset[ch] * 3 + (m == MSDR_MODE_LSB ? 0 : m == MSDR_MODE_USB ? 1 : 2);
+                }
+                rc = upload(ctx, fs, &c->d_fset);
+            }
+        }
     }
     for (uint32_t k = 0; k < c->nnodes && !rc; k++) {
         if (cfg->node_stages[k] < 1 || cfg->node_stages[k] > 4 || !cfg->node_coefs[k]) { rc = fail(MSDR_STATUS_ARGUMENT_ERROR, "biquad node %u misconfigured", k); break; }
@@ -718,8 +793,16 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     p.phase0 = (int)c->phase; p.in_scale = c->in_scale; p.sqrt_kind = c->sqrt_kind;
     p.nstages = (int)c->nstages; p.bq = c->d_bq; p.bq_state = c->d_bq_state;
 
+    // ---- kernel choice: the folded kernel needs a short-period oscillator; AM additionally the exact Fs/4 pattern
+    bool use_fold = f32 && c->fold_P > 0;
+    if (use_fold && !c->fold_fs4_exact)
+        for (int m : c->h_mode) if (m != MSDR_MODE_LSB && m != MSDR_MODE_USB) { use_fold = false; break; }
+    const int kTile = use_fold ? kFoldTile : kChainTile;
+    p.ftaps = c->d_ftaps; p.chan_fset = c->d_fset; p.fold_period = c->fold_P; p.bq_fold = c->d_bq_fold;
+    p.fold_rot = c->fold_P ? (int)(c->phase % c->fold_P) : 0;
+
     // ---- time segmentation (DESIGN.md "IIR along time") ------------------------------------------
-    const long long tiles = ((long long)n_samples + kChainTile - 1) / kChainTile;
+    const long long tiles = ((long long)n_samples + kTile - 1) / kTile;
     long long warm_tiles = 0;
     bool can_split = true;
     if (c->nstages) {
@@ -728,7 +811,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             if (c->pole_radius >= 0.99999) can_split = false;        // marginal/unstable: never re-converges
             else if (c->pole_radius > 0) w = (long long)std::ceil(std::log(1e-10) / std::log(c->pole_radius)) + 64 * c->nstages;
         }
-        warm_tiles = (w + kChainTile - 1) / kChainTile;
+        warm_tiles = (w + kTile - 1) / kTile;
         if (warm_tiles > 64) can_split = false;
     }
     long long nseg = 1;
@@ -741,16 +824,20 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     }
     long long seg_tiles = (tiles + nseg - 1) / nseg;
     nseg = (tiles + seg_tiles - 1) / seg_tiles;
-    p.nseg = (int)nseg; p.seg_len = seg_tiles * kChainTile; p.warm = (int)(nseg > 1 ? warm_tiles * kChainTile : 0);
+    p.nseg = (int)nseg; p.seg_len = seg_tiles * kTile; p.warm = (int)(nseg > 1 ? warm_tiles * kTile : 0);
 
-    const size_t lds = chain_lds_bytes(p.ntaps_pad);
+    const size_t lds = use_fold ? fold_lds_bytes(p.ntaps_pad) : chain_lds_bytes(p.ntaps_pad);
     const unsigned grid = (unsigned)(c->channels * nseg);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && c->events.size() < 8192) {
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, c->ctx->stream));
     }
-    if (f32) hipLaunchKernelGGL((chain_kernel<ArithF32>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p);
+    const char *kname = f32 ? "chain_kernel<ArithF32>" : "chain_kernel<ArithQ15>";
+    if (use_fold && c->fold_P == 4) { hipLaunchKernelGGL((chain_fold_kernel<4>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<4>"; }
+    else if (use_fold && c->fold_P == 2) { hipLaunchKernelGGL((chain_fold_kernel<2>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<2>"; }
+    else if (use_fold) { hipLaunchKernelGGL((chain_fold_kernel<1>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<1>"; }
+    else if (f32) hipLaunchKernelGGL((chain_kernel<ArithF32>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p);
     else     hipLaunchKernelGGL((chain_kernel<ArithQ15>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p);
     if (int rc = launch_check("chain_kernel")) return rc;
     if (e0) { HIP_TRY(hipEventRecord(e1, c->ctx->stream)); c->events.emplace_back(e0, e1); }
@@ -765,9 +852,9 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     c->cur ^= 1;
     c->phase = (c->phase + (long long)(n_samples % c->osc_len)) % c->osc_len;
 
-    snprintf(c->info.kernel, sizeof c->info.kernel, "%s", f32 ? "chain_kernel<ArithF32>" : "chain_kernel<ArithQ15>");
+    snprintf(c->info.kernel, sizeof c->info.kernel, "%s", kname);
     c->info.grid = grid; c->info.block = kThreads; c->info.lds_bytes = (uint32_t)lds;
-    c->info.time_segments = (uint32_t)nseg; c->info.warmup = (uint32_t)p.warm; c->info.tile = kChainTile;
+    c->info.time_segments = (uint32_t)nseg; c->info.warmup = (uint32_t)p.warm; c->info.tile = (uint32_t)kTile;
     c->info.taps_padded = c->ntaps_pad;
     return 0;
 }
@@ -791,6 +878,11 @@ extern "C" int msdr_chain_set_mode(msdr_chain *c, uint32_t channel, int32_t mode
     if (int rc = bind(c->ctx)) return rc;
     if (channel >= c->channels || mode < MSDR_MODE_SYNCAM || mode > MSDR_MODE_CW || tapset < 0 || (uint32_t)tapset >= c->tapsets)
         return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad channel/mode/tapset");
+    c->h_mode[channel] = mode; c->h_tapset[channel] = tapset;
+    if (c->d_fset) {
+        const int fs = tapset * 3 + (mode == MSDR_MODE_LSB ? 0 : mode == MSDR_MODE_USB ? 1 : 2);
+        HIP_TRY(hipMemcpyAsync(c->d_fset + channel, &fs, sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));
+    }
     HIP_TRY(hipMemcpyAsync(c->d_mode + channel, &mode, sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));
     HIP_TRY(hipMemcpyAsync(c->d_tapset + channel, &tapset, sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));
     HIP_TRY(hipStreamSynchronize(c->ctx->stream));

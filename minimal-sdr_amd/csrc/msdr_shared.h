@@ -14,6 +14,10 @@ constexpr int kChainTile = kThreads * kChainR;  // 2560 output samples per workg
 // Single-stream FIR (arm_fir_f32 / arm_fir_fast_q15 mirrors): 4-byte elements, lane stride R/4 slots.
 constexpr int kFirR      = 12;                  // 3 slots: odd
 constexpr int kFirTile   = kThreads * kFirR;    // 3072
+// Folded fp32 chain: one float per sample in LDS, 12 outputs per lane (3 slots: odd), and 12 is a
+// multiple of every supported NCO period (1, 2, 4), so a lane's r-th output always has phase r mod P.
+constexpr int kFoldR     = 12;
+constexpr int kFoldTile  = kThreads * kFoldR;   // 3072
 // Biquad-only kernel (arm_biquad_cascade_df1_f32 mirror)
 constexpr int kBqR       = 8;
 constexpr int kBqTile    = kThreads * kBqR;     // 2048
@@ -59,6 +63,12 @@ struct ChainParams {
     int nstages;               // F32 biquad stages
     const BiquadStageTables<kChainR> *bq;   // [nstages]
     float *bq_state;           // [channels][kMaxStages][4] = x1,x2,y1,y2
+    // folded F32 kernel (mixer folded into the taps; see DESIGN.md "Tap folding")
+    const float *ftaps;        // [fsets][P rotations][steps][PE rows][2][2] folded tap pairs, in_scale included
+    const int *chan_fset;      // [channels] folded-set index
+    int fold_period;           // P: NCO period in samples (1, 2 or 4)
+    int fold_rot;              // (absolute index of sample 0 of this call) mod P
+    const BiquadStageTables<kFoldR> *bq_fold;   // [nstages], lanes own kFoldR samples
 };
 
 }  // namespace msdr

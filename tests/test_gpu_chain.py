@@ -230,3 +230,71 @@ def test_chain_f32_mixed_modes_many_channels(ctx, orc):
     want3 = orc.chain_f32(x[3], orclib.USB, hi, hq, sin4, cos4, bq)
     assert rel_rms(got2[3], want3) < TOL
     assert np.array_equal(got2[5], got[5])
+
+
+# ---------------------------------------------------------------- fp32, folded kernel -------
+def _q15_nco(p, cycles, length=128):
+    """freq_conv-style tables: q15 oscillator tables (Osc_I/Q_buffer_i) converted like arm_q15_to_float;
+    exactly periodic with period p samples."""
+    n = np.arange(length)
+    s = np.round(32767 * np.sin(2 * np.pi * cycles * n / p)).astype(np.int16)
+    c = np.round(32767 * np.cos(2 * np.pi * cycles * n / p)).astype(np.int16)
+    return (s / 32768.0).astype(np.float32), (c / 32768.0).astype(np.float32)
+
+
+@pytest.mark.parametrize("period", [1, 2, 4])
+@pytest.mark.parametrize("block", [None, 333, 128, 3073])
+@pytest.mark.parametrize("mode", [orclib.LSB, orclib.USB])
+def test_chain_f32_folded_ssb_vs_oracle(ctx, orc, period, block, mode):
+    """Short-period oscillators take the folded kernel (mixer folded into the taps).  Odd block
+    lengths rotate the oscillator phase between calls and misalign the rows of channels > 0."""
+    rng = np.random.default_rng(100 + period)
+    hi, hq = _hilbert_pair(100)
+    oi, oq = _q15_nco(period, 1)
+    bq = _f32_biquads(orc, 2)
+    x = rng.integers(-8000, 8001, (3, 7001)).astype(np.int16)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 3, hi, hq, mixer=msdr.MIXER_NCO, mode=mode, osc_i=oi, osc_q=oq, biquad_coeffs=bq)
+    got = run_chain(ctx, chain, x, np.float32, block)
+    assert chain.info()["kernel"] == "chain_fold_kernel<%d>" % period
+    for c in range(3):
+        want = orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq)
+        assert rel_rms(got[c], want) < TOL, (c, rel_rms(got[c], want))
+    # the as-written kernel (MSDR_CHAIN_NO_TAP_FOLDING) agrees with the same oracle
+    plain = msdr.Chain(ctx, msdr.ARITH_F32, 3, hi, hq, mixer=msdr.MIXER_NCO, mode=mode, osc_i=oi, osc_q=oq, biquad_coeffs=bq,
+                       flags=msdr.CHAIN_NO_TAP_FOLDING)
+    got2 = run_chain(ctx, plain, x, np.float32, block)
+    assert plain.info()["kernel"] == "chain_kernel<ArithF32>"
+    for c in range(3):
+        assert rel_rms(got2[c], orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq)) < TOL
+
+
+@pytest.mark.parametrize("block", [None, 129, 1000])
+def test_chain_f32_folded_am_fs4_odd_blocks(ctx, orc, block):
+    """AM through the folded kernel (Fs/4 zero skipping) with block lengths that leave the mixer at
+    every phase 0..3 at a call boundary."""
+    rng = np.random.default_rng(77)
+    lp = (np.sinc(2 * 2800 / 24000 * (np.arange(62) - 30.5)) * np.kaiser(62, 7.0)).astype(np.float32)
+    lp /= lp.sum()
+    x = rng.integers(-8000, 8001, (2, 5003)).astype(np.int16)
+    bq = _f32_biquads(orc, 1)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 2, lp, lp, mixer=msdr.MIXER_FS4, mode=orclib.AM, biquad_coeffs=bq)
+    got = run_chain(ctx, chain, x, np.float32, block)
+    assert chain.info()["kernel"] == "chain_fold_kernel<4>"
+    cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+    for c in range(2):
+        assert rel_rms(got[c], orc.chain_f32(x[c], orclib.AM, lp, lp, sin4, cos4, bq)) < TOL
+
+
+def test_chain_f32_am_with_non_fs4_nco_uses_general_kernel(ctx, orc):
+    """AM can only be folded for the exact Fs/4 pattern; a q15-rounded fs/4 table (0.99997) must fall
+    back to the as-written kernel and still match."""
+    rng = np.random.default_rng(78)
+    hi, hq = _hilbert_pair(100)
+    oi, oq = _q15_nco(4, 1)
+    x = rng.integers(-8000, 8001, (2, 4000)).astype(np.int16)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 2, hi, hq, mixer=msdr.MIXER_NCO, modes=np.array([orclib.AM, orclib.LSB], np.int32),
+                       osc_i=oi, osc_q=oq)
+    got = run_chain(ctx, chain, x, np.float32)
+    assert chain.info()["kernel"] == "chain_kernel<ArithF32>"
+    for c, m in enumerate((orclib.AM, orclib.LSB)):
+        assert rel_rms(got[c], orc.chain_f32(x[c], m, hi, hq, oi, oq, None)) < TOL

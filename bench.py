@@ -255,24 +255,24 @@ def main():
     kernel_ms, launches = chain.kernel_time()
     chain.enable_timing(False)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        import msdr_dist
+        dt = msdr_dist.max_over_ranks(dt, dev)
 
     gather = None
     if dist is not None:                                       # RCCL gather of demodulated audio, timed on its own
-        m = min(ch * n, 1 << 24)
-        part = y.view(-1)[:m].contiguous()
-        full = torch.empty((world * m,), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(full, part)
+        rows = max(1, min(ch, (1 << 24) // n)) if n <= (1 << 24) else 1
+        cols = min(n, 1 << 24)
+        part = y[:rows, :cols].contiguous()                    # a bounded slice of this rank's audio shard
+        full = msdr_dist.gather_audio(part, world * rows)
         barrier()
         g0 = time.perf_counter()
         reps = 5
         for _ in range(reps):
-            dist.all_gather_into_tensor(full, part)
+            full = msdr_dist.gather_audio(part, world * rows)
         barrier()
         gdt = (time.perf_counter() - g0) / reps
-        gather = {"op": "all_gather_into_tensor (RCCL)", "bytes_per_rank": m * 4, "ms": round(gdt * 1e3, 3),
+        m = rows * cols
+        gather = {"op": "msdr_dist.gather_audio = all_gather_into_tensor over RCCL", "bytes_per_rank": m * 4, "ms": round(gdt * 1e3, 3),
                   "GBps_into_each_rank": round((world - 1) * m * 4 / gdt / 1e9, 1),
                   "Msamples_per_s": round(world * m / gdt / 1e6, 1)}
 

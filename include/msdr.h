@@ -88,6 +88,7 @@ int msdr_malloc(msdr_ctx *ctx, size_t bytes, void **d_ptr);
 int msdr_free(msdr_ctx *ctx, void *d_ptr);
 int msdr_memcpy_h2d(msdr_ctx *ctx, void *d_dst, const void *src, size_t bytes);   /* stream-ordered, returns after the copy */
 int msdr_memcpy_d2h(msdr_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+int msdr_memcpy_d2d(msdr_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);     /* stream-ordered, asynchronous */
 int msdr_memset(msdr_ctx *ctx, void *d_dst, int value, size_t bytes);
 
 /* ======================================================================================

@@ -51,6 +51,8 @@ struct msdr_ctx {
     int device;
     hipStream_t stream;
     bool owns_stream;
+    void *scratch;          // small device buffer reused for per-call host tables (oscillator tables)
+    size_t scratch_bytes;
 };
 
 static int bind(msdr_ctx *ctx)
@@ -88,6 +90,7 @@ extern "C" int msdr_ctx_create(int device, void *hip_stream, msdr_ctx **out)
     msdr_ctx *c = new (std::nothrow) msdr_ctx();
     if (!c) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
     c->device = device;
+    c->scratch = nullptr; c->scratch_bytes = 0;
     c->owns_stream = (hip_stream == nullptr);
     c->stream = (hipStream_t)hip_stream;
     if (c->owns_stream) {
@@ -103,6 +106,7 @@ extern "C" int msdr_ctx_destroy(msdr_ctx *ctx)
     if (!ctx) return 0;
     if (int rc = bind(ctx)) return rc;
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -142,6 +146,12 @@ extern "C" int msdr_memcpy_d2h(msdr_ctx *ctx, void *dst, const void *d_src, size
     if (int rc = bind(ctx)) return rc;
     HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int msdr_memcpy_d2d(msdr_ctx *ctx, void *d_dst, const void *d_src, size_t bytes)
+{
+    if (int rc = bind(ctx)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
 extern "C" int msdr_memset(msdr_ctx *ctx, void *d_dst, int value, size_t bytes)
@@ -508,18 +518,21 @@ static int freqconv_common(msdr_ctx *ctx, T *d_i, T *d_q, const T *osc_i, const 
     if (!osc_i || !osc_q || osc_len == 0) return fail(MSDR_STATUS_ARGUMENT_ERROR, "oscillator tables missing");
     long long total = (long long)channels * blockSize;
     if (total == 0) return 0;
-    std::vector<T> hi(osc_i, osc_i + osc_len), hq(osc_q, osc_q + osc_len);
-    T *di = nullptr, *dq = nullptr;
-    int rc = upload(ctx, hi, &di);
-    if (!rc) rc = upload(ctx, hq, &dq);
-    if (!rc) {
-        hipLaunchKernelGGL(kernel, dim3(grid_1d(total)), dim3(256), 0, ctx->stream, d_i, d_q, (const T *)di, (const T *)dq,
-                           (int)osc_len, dir ? 1 : 0, total, (int)blockSize);
-        rc = launch_check(name);
-        (void)hipStreamSynchronize(ctx->stream);
+    // the two host tables go through the context's scratch buffer (grown on demand, reused between calls)
+    const size_t need = 2 * (size_t)osc_len * sizeof(T);
+    if (ctx->scratch_bytes < need) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) (void)hipFree(ctx->scratch);
+        ctx->scratch = nullptr; ctx->scratch_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->scratch, std::max<size_t>(need, 4096)));
+        ctx->scratch_bytes = std::max<size_t>(need, 4096);
     }
-    hipFree(di); hipFree(dq);
-    return rc;
+    T *di = (T *)ctx->scratch, *dq = di + osc_len;
+    HIP_TRY(hipMemcpyAsync(di, osc_i, osc_len * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dq, osc_q, osc_len * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(kernel, dim3(grid_1d(total)), dim3(256), 0, ctx->stream, d_i, d_q, (const T *)di, (const T *)dq,
+                       (int)osc_len, dir ? 1 : 0, total, (int)blockSize);
+    return launch_check(name);
 }
 extern "C" int msdr_freqconv_q15(msdr_ctx *ctx, q15_t *d_i, q15_t *d_q, const q15_t *osc_i, const q15_t *osc_q, uint32_t osc_len,
                                  int dir, int pass, uint32_t channels, uint32_t blockSize)

@@ -28,7 +28,7 @@ for name in ("fetch", "write"):
     tot, cnt = 0.0, 0
     for f in glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "chain_kernel" in r.get("Kernel_Name", ""):
+            if "chain_" in r.get("Kernel_Name", "") and "kernel" in r.get("Kernel_Name", ""):
                 tot += float(r.get("Counter_Value", 0)); cnt += 1
     res[name] = (tot, cnt)
     print("%s counter: %d chain_kernel dispatches, mean raw value %.1f" % (name.upper() + "_SIZE", cnt, tot / cnt if cnt else float("nan")))

@@ -209,37 +209,60 @@ extern "C" int msdr_biquad_design(int kind, float frequency, float q_or_gain, fl
     return 0;
 }
 
-// tables for the parallel df1 stage (see BiquadStageTables)
+// tables for the parallel df1 cascade (see BiquadCascadeTables in msdr_shared.h)
 template <int L>
-static void make_stage_tables(const float *c, BiquadStageTables<L> *T)
+static void make_cascade_tables(const float *coeffs, int stages, BiquadCascadeTables<L> *T)
 {
     memset(T, 0, sizeof *T);
-    T->b0 = c[0]; T->b1 = c[1]; T->b2 = c[2]; T->a1 = c[3]; T->a2 = c[4];
-    const double a1 = c[3], a2 = c[4];
-    // alpha/beta: homogeneous responses to (y[-1], y[-2]) = (1,0) and (0,1)
-    double am1 = 1, am2 = 0, bm1 = 0, bm2 = 1, al[L], be[L];
-    for (int j = 0; j < L; j++) {
-        al[j] = a1 * am1 + a2 * am2; be[j] = a1 * bm1 + a2 * bm2;
-        am2 = am1; am1 = al[j]; bm2 = bm1; bm1 = be[j];
-        T->alpha[j] = (float)al[j]; T->beta[j] = (float)be[j];
+    T->nstages = stages;
+    // combined numerator C(z) = prod_s (b0 + b1 z^-1 + b2 z^-2)
+    std::vector<double> num(1, 1.0);
+    for (int s = 0; s < stages; s++) {
+        std::vector<double> nx(num.size() + 2, 0.0);
+        for (size_t i = 0; i < num.size(); i++)
+            for (int k = 0; k < 3; k++) nx[i + k] += num[i] * (double)coeffs[5 * s + k];
+        num.swap(nx);
     }
-    double M[4] = {al[L - 1], be[L - 1], al[L - 2], be[L - 2]};
+    if (stages == 0) num.assign(1, 1.0);
+    for (size_t i = 0; i < num.size() && i < 12; i++) T->num[i] = (float)num[i];
     auto mul = [](const double *A, const double *B, double *C) {
         double r[4] = {A[0] * B[0] + A[1] * B[2], A[0] * B[1] + A[1] * B[3], A[2] * B[0] + A[3] * B[2], A[2] * B[1] + A[3] * B[3]};
         memcpy(C, r, sizeof r);
     };
-    double P[4];
-    memcpy(P, M, sizeof P);
-    for (int k = 0; k < 6; k++) {
-        for (int i = 0; i < 4; i++) T->mpow[k][i] = (float)P[i];
-        mul(P, P, P);
-    }
-    for (int i = 0; i < 4; i++) T->m64[i] = (float)P[i];
-    double Q[4];
-    memcpy(Q, M, sizeof Q);
-    for (int l = 0; l < 64; l++) {
-        for (int i = 0; i < 4; i++) T->mlane[l][i] = (float)Q[i];
-        mul(Q, M, Q);
+    for (int s = 0; s < stages; s++) {
+        auto &Q = T->sec[s];
+        Q.a1 = coeffs[5 * s + 3]; Q.a2 = coeffs[5 * s + 4];
+        const double a1 = Q.a1, a2 = Q.a2;
+        // impulse response g and homogeneous responses alpha/beta of  y[n] = a1 y[n-1] + a2 y[n-2]
+        double g[L + 1], gm1 = 1.0, gm2 = 0.0;      // g[0] = 1
+        g[0] = 1.0;
+        for (int k = 1; k <= L; k++) { g[k] = a1 * gm1 + a2 * gm2; gm2 = gm1; gm1 = g[k]; }
+        for (int j = 0; j < L; j++) {
+            Q.g[j][0] = (float)g[L - 1 - j];
+            Q.g[j][1] = (L - 2 - j >= 0) ? (float)g[L - 2 - j] : 0.0f;
+        }
+        double am1 = 1, am2 = 0, bm1 = 0, bm2 = 1, al[L], be[L];
+        for (int j = 0; j < L; j++) {
+            al[j] = a1 * am1 + a2 * am2; be[j] = a1 * bm1 + a2 * bm2;
+            am2 = am1; am1 = al[j]; bm2 = bm1; bm1 = be[j];
+        }
+        double M[4] = {al[L - 1], be[L - 1], al[L - 2], be[L - 2]};      // row-major
+        double P[4];
+        memcpy(P, M, sizeof P);
+        for (int k = 0; k < 6; k++) {
+            if (k < 4) {
+                Q.mcol[k][0][0] = (float)P[0]; Q.mcol[k][0][1] = (float)P[2];   // column 0 = (M00, M10)
+                Q.mcol[k][1][0] = (float)P[1]; Q.mcol[k][1][1] = (float)P[3];   // column 1 = (M01, M11)
+            }
+            mul(P, P, P);
+        }
+        for (int i = 0; i < 4; i++) Q.m64[i] = (float)P[i];
+        double W[4];
+        memcpy(W, M, sizeof W);
+        for (int l = 0; l < 64; l++) {
+            Q.mlane[l][0] = (float)W[0]; Q.mlane[l][1] = (float)W[2]; Q.mlane[l][2] = (float)W[1]; Q.mlane[l][3] = (float)W[3];
+            mul(W, M, W);
+        }
     }
 }
 
@@ -375,8 +398,8 @@ extern "C" int msdr_fir_f32_destroy(msdr_fir_f32 *S) { return fir_destroy(S); }
 struct msdr_biquad_df1_f32 {
     msdr_ctx *ctx;
     uint32_t channels, stages;
-    BiquadStageTables<kBqR> *d_tabs;
-    float *d_state;   // [channels][kMaxStages][4]
+    BiquadCascadeTables<kBqR> *d_tabs;
+    float *d_state;   // [channels][kBqStateFloats]
 };
 
 extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, const float32_t *pCoeffs, uint32_t channels,
@@ -390,10 +413,10 @@ extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, cons
     msdr_biquad_df1_f32 *S = new (std::nothrow) msdr_biquad_df1_f32();
     if (!S) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
     S->ctx = ctx; S->channels = channels; S->stages = numStages; S->d_tabs = nullptr; S->d_state = nullptr;
-    std::vector<BiquadStageTables<kBqR>> tabs(std::max<int>(numStages, 1));
-    for (int s = 0; s < numStages; s++) make_stage_tables<kBqR>(pCoeffs + 5 * s, &tabs[s]);
+    std::vector<BiquadCascadeTables<kBqR>> tabs(1);
+    make_cascade_tables<kBqR>(pCoeffs, numStages, &tabs[0]);
     int rc = upload(ctx, tabs, &S->d_tabs);
-    if (!rc) rc = dzalloc(ctx, (size_t)channels * kMaxStages * 4, &S->d_state);
+    if (!rc) rc = dzalloc(ctx, (size_t)channels * kBqStateFloats, &S->d_state);
     if (rc) { hipFree(S->d_tabs); hipFree(S->d_state); delete S; return rc; }
     *out = S;
     return 0;
@@ -404,15 +427,19 @@ extern "C" int msdr_biquad_df1_f32_process(msdr_biquad_df1_f32 *S, const float32
     if (int rc = bind(S->ctx)) return rc;
     if (blockSize == 0) return 0;
     if (!d_src || !d_dst) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    if (S->stages == 0) {      // empty cascade: pass-through
+        if (d_src != d_dst) HIP_TRY(hipMemcpyAsync(d_dst, d_src, (size_t)S->channels * blockSize * sizeof(float), hipMemcpyDeviceToDevice, S->ctx->stream));
+        return 0;
+    }
     hipLaunchKernelGGL(biquad_df1_kernel, dim3(S->channels), dim3(kThreads), 0, S->ctx->stream, d_src, d_dst,
-                       (long long)blockSize, (int)S->stages, (const BiquadStageTables<kBqR> *)S->d_tabs, S->d_state);
+                       (long long)blockSize, (const BiquadCascadeTables<kBqR> *)S->d_tabs, S->d_state);
     return launch_check("biquad_df1_kernel");
 }
 extern "C" int msdr_biquad_df1_f32_reset(msdr_biquad_df1_f32 *S)
 {
     if (!S) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
     if (int rc = bind(S->ctx)) return rc;
-    HIP_TRY(hipMemsetAsync(S->d_state, 0, (size_t)S->channels * kMaxStages * 4 * sizeof(float), S->ctx->stream));
+    HIP_TRY(hipMemsetAsync(S->d_state, 0, (size_t)S->channels * kBqStateFloats * sizeof(float), S->ctx->stream));
     return 0;
 }
 extern "C" int msdr_biquad_df1_f32_destroy(msdr_biquad_df1_f32 *S)
@@ -587,14 +614,14 @@ struct msdr_chain {
     int16_t *d_hist[2];
     int cur;
     long long phase;                  // absolute sample index modulo the NCO period
-    BiquadStageTables<kChainR> *d_bq;
+    BiquadCascadeTables<kChainR> *d_bq;
     float *d_bq_state;
     // folded F32 path (msdr_chain_fold.hiph)
     int fold_P;                       // 0 = not foldable; else NCO period 1, 2 or 4
     bool fold_fs4_exact;              // oscillator is exactly {1,0,-1,0}/{0,1,0,-1}: AM can be folded too
     float *d_ftaps;                   // [tapsets*3][P rotations][steps][PE rows][2 pair-columns][2]
     int *d_fset;                      // [channels]
-    BiquadStageTables<kFoldR> *d_bq_fold;
+    BiquadCascadeTables<kFoldR> *d_bq_fold;
     std::vector<int> h_mode, h_tapset;
     msdr_biquad_q15 *nodes[2];
     msdr_chain_info info;
@@ -705,10 +732,10 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     if (!rc) rc = dzalloc(ctx, (size_t)c->channels * c->hist_len, &c->d_hist[0]);
     if (!rc) rc = dzalloc(ctx, (size_t)c->channels * c->hist_len, &c->d_hist[1]);
     if (!rc && f32) {
-        std::vector<BiquadStageTables<kChainR>> tabs(std::max<uint32_t>(c->nstages, 1));
-        for (uint32_t s = 0; s < c->nstages; s++) make_stage_tables<kChainR>(cfg->biquad_coeffs + 5 * s, &tabs[s]);
+        std::vector<BiquadCascadeTables<kChainR>> tabs(1);
+        make_cascade_tables<kChainR>(cfg->biquad_coeffs, (int)c->nstages, &tabs[0]);
         rc = upload(ctx, tabs, &c->d_bq);
-        if (!rc) rc = dzalloc(ctx, (size_t)c->channels * kMaxStages * 4, &c->d_bq_state);
+        if (!rc) rc = dzalloc(ctx, (size_t)c->channels * kBqStateFloats, &c->d_bq_state);
     }
     // ---- tap folding (F32): oscillator period, folded tables, per-channel folded-set index ----------
     c->fold_P = 0; c->fold_fs4_exact = false;
@@ -761,8 +788,8 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                         }
             rc = upload(ctx, ft, &c->d_ftaps);
             if (!rc) {
-                std::vector<BiquadStageTables<kFoldR>> tabs(std::max<uint32_t>(c->nstages, 1));
-                for (uint32_t s = 0; s < c->nstages; s++) make_stage_tables<kFoldR>(cfg->biquad_coeffs + 5 * s, &tabs[s]);
+                std::vector<BiquadCascadeTables<kFoldR>> tabs(1);
+                make_cascade_tables<kFoldR>(cfg->biquad_coeffs, (int)c->nstages, &tabs[0]);
                 rc = upload(ctx, tabs, &c->d_bq_fold);
             }
             if (!rc) {
@@ -879,7 +906,7 @@ extern "C" int msdr_chain_reset(msdr_chain *c)
     size_t hb = (size_t)c->channels * c->hist_len * sizeof(int16_t);
     HIP_TRY(hipMemsetAsync(c->d_hist[0], 0, hb, c->ctx->stream));
     HIP_TRY(hipMemsetAsync(c->d_hist[1], 0, hb, c->ctx->stream));
-    if (c->d_bq_state) HIP_TRY(hipMemsetAsync(c->d_bq_state, 0, (size_t)c->channels * kMaxStages * 4 * sizeof(float), c->ctx->stream));
+    if (c->d_bq_state) HIP_TRY(hipMemsetAsync(c->d_bq_state, 0, (size_t)c->channels * kBqStateFloats * sizeof(float), c->ctx->stream));
     // the reference never clears biquad history on retune (filter_biquad.cpp:95-97); init_FIR() only zeroes the FIR state.
     c->phase = 0;
     return 0;

@@ -24,20 +24,29 @@ constexpr int kBqTile    = kThreads * kBqR;     // 2048
 
 constexpr int kMaxStages = 4;
 
-// Host-precomputed tables for the in-workgroup parallel evaluation of one df1 biquad stage whose
-// lanes each own L consecutive samples (see DESIGN.md "IIR along time").
-//   y[n] = u[n] + a1 y[n-1] + a2 y[n-2],  u[n] = b0 x[n] + b1 x[n-1] + b2 x[n-2]
-//   homogeneous solution from (p,q) = (y[-1], y[-2]):  h[j] = alpha[j] p + beta[j] q
-//   lane transition M = [[alpha[L-1], beta[L-1]], [alpha[L-2], beta[L-2]]]
+// Host-precomputed tables for the in-workgroup parallel evaluation of a df1 biquad CASCADE whose lanes
+// each own L consecutive samples (DESIGN.md "IIR along time").  The cascade
+//     H(z) = prod_s (b0 + b1 z^-1 + b2 z^-2)_s / (1 - a1 z^-1 - a2 z^-2)_s
+// is evaluated as ONE numerator FIR  v = C(z) d,  C = prod_s B_s  (2S+1 taps, in registers), followed by
+// S all-pole sections  w_s[n] = w_(s-1)[n] + a1 w_s[n-1] + a2 w_s[n-2].  For an all-pole section:
+//   end state of a lane run from zero state   Z = sum_j (g[L-1-j], g[L-2-j]) v_j      (g = impulse response)
+//   lane transition                           (y[L-1], y[L-2]) = M (p, q) + Z
 template <int L>
-struct BiquadStageTables {
-    float b0, b1, b2, a1, a2;
-    float pad0[3];
-    float alpha[L], beta[L];
-    float mpow[6][4];     // M^(2^d), d = 0..5, row-major 2x2
-    float m64[4];         // M^64  (one whole wave)
-    float mlane[64][4];   // M^(l+1), l = lane in wave
+struct BiquadCascadeTables {
+    int nstages;
+    int pad0[3];
+    float num[2 * kMaxStages + 1 + 3];   // c_0 .. c_2S, zero padded to 12
+    struct Section {
+        float a1, a2;
+        float pad1[2];
+        float g[L][2];        // g[j] = (g_(L-1-j), g_(L-2-j))
+        float mcol[4][2][2];  // M^(2^k), k = 0..3, stored by columns: [k][col][row]
+        float m64[4];         // M^64 row-major 2x2 (one whole wave)
+        float mlane[64][4];   // M^(l+1) stored {M00, M10, M01, M11} (columns), l = lane in wave
+    } sec[kMaxStages];
 };
+// per-channel cascade state in HBM: 16 floats = d[n-1..n-8] (numerator history) | (w1, w2) per section
+constexpr int kBqStateFloats = 16;
 
 struct ChainParams {
     const int16_t *x;          // [channels][n] IF samples
@@ -61,14 +70,14 @@ struct ChainParams {
     float in_scale;
     int sqrt_kind;
     int nstages;               // F32 biquad stages
-    const BiquadStageTables<kChainR> *bq;   // [nstages]
-    float *bq_state;           // [channels][kMaxStages][4] = x1,x2,y1,y2
+    const BiquadCascadeTables<kChainR> *bq;
+    float *bq_state;           // [channels][kBqStateFloats]
     // folded F32 kernel (mixer folded into the taps; see DESIGN.md "Tap folding")
     const float *ftaps;        // [fsets][P rotations][steps][PE rows][2][2] folded tap pairs, in_scale included
     const int *chan_fset;      // [channels] folded-set index
     int fold_period;           // P: NCO period in samples (1, 2 or 4)
     int fold_rot;              // (absolute index of sample 0 of this call) mod P
-    const BiquadStageTables<kFoldR> *bq_fold;   // [nstages], lanes own kFoldR samples
+    const BiquadCascadeTables<kFoldR> *bq_fold;   // lanes own kFoldR samples
 };
 
 }  // namespace msdr

@@ -5,6 +5,14 @@ import sys
 import numpy as np
 import pytest
 
+# torch ships its own ROCm runtime; a process that uses both must load torch FIRST so that libmsdr.so binds
+# to the runtime torch already initialised (two HIP runtimes cannot both claim the GPU).  Tests that pass torch
+# buffers / streams to the library rely on this order.
+try:
+    import torch  # noqa: F401
+except ImportError:      # torch is optional for the GPU tests that use the library's own allocator
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "minimal-sdr_amd", "python"))
 import msdr  # noqa: E402,F401

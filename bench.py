@@ -160,6 +160,53 @@ def cpu_baseline(wl, x_host, gpu_first, target_s=12.0):
                       "1-thread rate %.2f Msamples/s)" % (xs.shape[0], per_row, passes, total_dt, rate1 / 1e6)}, worst, min(per_row, gpu_first.shape[1])
 
 
+def cpu_baseline_q15(wl, x_host, gpu_first, target_s=12.0):
+    """Same as cpu_baseline for the integer chain (orc_chain_q15_batch); parity = number of differing samples."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orclib
+    orc = orclib.Oracle()
+    threads = os.cpu_count() or 1
+    rows = x_host.shape[0]
+    n = (x_host.shape[1] // 128) * 128
+    modes_all = wl["modes"] if wl["modes"] is not None else np.full(wl["channels"], wl["mode"], np.int32)
+    tapsets_all = wl["tapsets"] if wl["tapsets"] is not None else np.zeros(wl["channels"], np.int32)
+    nodes = [orc.biquad_teensy_new(c) for c in wl["qnodes"]]
+    oi, oq = wl["qosc"] if wl["qosc"] else (None, None)
+
+    def run(xs, modes, ts, thr):
+        t0 = time.perf_counter()
+        outs = np.empty(xs.shape, np.int16)
+        used = 1
+        for s_ in sorted(set(ts.tolist())):
+            idx = np.nonzero(ts == s_)[0]
+            o, used = orc.chain_q15_batch(xs[idx], modes[idx], wl["qi"][s_], wl["qq"][s_], mixer=1 if oi is not None else 0,
+                                          osc_i=oi, osc_q=oq, biquads=nodes, threads=thr)
+            outs[idx] = o
+        return outs, time.perf_counter() - t0, used
+
+    if rows == 1:
+        chunks = max(1, min(threads, n // 65536))
+        per_row = (n // chunks // 128) * 128
+        xs = np.ascontiguousarray(x_host[0, :chunks * per_row].reshape(chunks, per_row))
+        modes, ts = np.full(chunks, modes_all[0], np.int32), np.full(chunks, tapsets_all[0], np.int32)
+    else:
+        per_row = n
+        xs, modes, ts = np.ascontiguousarray(x_host[:, :n]), modes_all[:rows], tapsets_all[:rows]
+    total_dt, passes, outs, used = 0.0, 0, None, 1
+    while total_dt < target_s and passes < 50:
+        outs, dt, used = run(xs, modes, ts, threads)
+        total_dt += dt
+        passes += 1
+    rate = xs.size * passes / total_dt
+    m = min(per_row, gpu_first.shape[1])
+    bad = 0
+    for r in ([0] if rows == 1 else range(xs.shape[0])):
+        bad += int((outs[r, :m] != gpu_first[r, :m]).sum())
+    return {"value": round(rate / 1e6, 3), "unit": "Msamples/s", "cores": int(min(used, xs.shape[0])), "kind": "port",
+            "sample": "%d row(s) x %d samples of the same IF input, %d pass(es), %.1f s wall (oracle/msdr_oracle.c orc_chain_q15)"
+                      % (xs.shape[0], per_row, passes, total_dt)}, bad, m
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +218,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-fold", action="store_true", help="keep mixer and FIR as separate arithmetic steps")
     ap.add_argument("--time-segments", type=int, default=0)
+    ap.add_argument("--arith", default="f32", choices=["f32", "q15"],
+                    help="f32 = the north-star flavour (default); q15 = the reference as written (int16 out, bit-exact)")
     ap.add_argument("--osc-period", type=int, default=4, help="experiment: NCO period in samples (4 = fs/4, the named config)")
     ap.add_argument("--stages", type=int, default=-1, help="experiment: override the number of biquad stages (0..2)")
     ap.add_argument("--taps", type=int, default=0, help="experiment: override the tap count (same designer)")
@@ -222,12 +271,24 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx = msdr.Context(local_rank, stream.cuda_stream)
-    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, wl["ci"], wl["cq"], mixer=wl["mixer"], mode=wl["mode"], modes=wl["modes"],
-                       tapsets=wl["tapsets"], osc_i=wl["osc"][0] if wl["osc"] else None, osc_q=wl["osc"][1] if wl["osc"] else None,
-                       biquad_coeffs=wl["bq"] if len(wl["bq"]) else None, time_segments=args.time_segments,
-                       flags=msdr.CHAIN_NO_TAP_FOLDING if args.no_fold else 0)
+    q15 = args.arith == "q15"
+    if q15:       # the same workload through the as-written integer chain: Q15 taps / oscillator, Teensy biquad nodes
+        corr = msdr.AUDIO_SAMPLE_RATE_EXACT / FS
+        wl["qi"] = [np.round(np.asarray(c, np.float64) * 32767).astype(np.int16) for c in wl["ci"]]
+        wl["qq"] = [np.round(np.asarray(c, np.float64) * 32767).astype(np.int16) for c in wl["cq"]]
+        wl["qosc"] = tuple(np.round(np.asarray(o, np.float64) * 32768).clip(-32768, 32767).astype(np.int16) for o in wl["osc"]) if wl["osc"] else None
+        wl["qnodes"] = [[msdr.biquad_design(msdr.BQ_LOWPASS, np.float32(6000 * 0.9 * corr), 0.54)],
+                        [msdr.biquad_design(msdr.BQ_NOTCH, np.float32(FS / 8 * corr), 15.0)]][:len(wl["bq"])]
+        chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, wl["qi"], wl["qq"], mixer=wl["mixer"], mode=wl["mode"], modes=wl["modes"],
+                           tapsets=wl["tapsets"], osc_i=wl["qosc"][0] if wl["qosc"] else None,
+                           osc_q=wl["qosc"][1] if wl["qosc"] else None, biquad_nodes=wl["qnodes"])
+    else:
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, wl["ci"], wl["cq"], mixer=wl["mixer"], mode=wl["mode"], modes=wl["modes"],
+                           tapsets=wl["tapsets"], osc_i=wl["osc"][0] if wl["osc"] else None, osc_q=wl["osc"][1] if wl["osc"] else None,
+                           biquad_coeffs=wl["bq"] if len(wl["bq"]) else None, time_segments=args.time_segments,
+                           flags=msdr.CHAIN_NO_TAP_FOLDING if args.no_fold else 0)
     x = synth_if(torch, dev, ch, n, wl["seed"])
-    y = torch.empty((ch, n), dtype=torch.float32, device=dev)
+    y = torch.empty((ch, n), dtype=torch.int16 if q15 else torch.float32, device=dev)
     torch.cuda.synchronize(dev)
 
     def barrier():
@@ -285,7 +346,7 @@ def main():
     samples_per_step = ch * n
     value = world * samples_per_step * args.steps / dt / 1e6
     k_ms = kernel_ms / max(launches, 1)
-    alg_bytes = 6.0 * samples_per_step                          # int16 in + fp32 out
+    alg_bytes = (4.0 if q15 else 6.0) * samples_per_step        # int16 in + fp32 (or int16) out
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     extra = (6 if wl["mixer"] == msdr.MIXER_NCO else 0) + 4 + 9 * len(wl["bq"])
     flop_written = 4.0 * wl["taps"] + extra                      # as the reference writes it: two N-tap FIRs
@@ -295,9 +356,9 @@ def main():
         "metric": "Msamples/s through IF->I/Q->FIR->demod->IIR chain; achieved HBM GB/s vs peak",
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "q15 (int16 data, int32 accumulate)" if q15 else "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "channels_per_gpu": ch, "samples_per_channel_per_step": n, "taps": wl["taps"],
-                   "biquad_stages": int(len(wl["bq"])), "in": "int16", "out": "fp32", "sharding": "independent channels per GPU, no data-path collective",
+                   "biquad_stages": int(len(wl["bq"])), "in": "int16", "out": "int16" if q15 else "fp32", "sharding": "independent channels per GPU, no data-path collective",
                    "kernel": info["kernel"], "grid": info["grid"], "time_segments": info["time_segments"], "iir_warmup": info["warmup"],
                    "tap_folding": not args.no_fold},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -312,9 +373,9 @@ def main():
         out["gather"] = gather
     if not args.no_cpu and world == 1:
         x_host = x[:first_rows, :keep_x].cpu().numpy()
-        cb, worst, per_row = cpu_baseline(wl, x_host, gpu_first)
+        cb, worst, per_row = cpu_baseline_q15(wl, x_host, gpu_first) if q15 else cpu_baseline(wl, x_host, gpu_first)
         out["cpu_baseline"] = cb
-        out["parity"] = {"rel_rms_worst": float("%.3g" % worst), "tolerance": 1e-5, "rows": int(min(first_rows, max(1, x_host.shape[0]))),
+        out["parity"] = {("mismatching_samples" if q15 else "rel_rms_worst"): float("%.3g" % worst), "tolerance": 0 if q15 else 1e-5, "rows": int(min(first_rows, max(1, x_host.shape[0]))),
                          "samples_per_row": int(per_row)}
     elif not args.no_cpu:
         out["cpu_baseline"] = None

@@ -503,8 +503,8 @@ extern "C" int msdr_biquad_q15_update(msdr_biquad_q15 *S, q15_t *d_data, uint32_
     if (blockSize == 0) return 0;
     if (!d_data) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
     if (blockSize & 1u) return fail(MSDR_STATUS_LENGTH_ERROR, "AudioFilterBiquad processes sample pairs: blockSize must be even");
-    hipLaunchKernelGGL(biquad_teensy_kernel, dim3((S->channels + 63) / 64), dim3(64), 0, S->ctx->stream, d_data, S->d_defs,
-                       (int)S->channels, (long long)blockSize);
+    hipLaunchKernelGGL((biquad_teensy_kernel<1>), dim3((S->channels + 63) / 64), dim3(64), 0, S->ctx->stream, d_data, S->d_defs,
+                       (int *)nullptr, (int)S->channels, (long long)blockSize);
     return launch_check("biquad_teensy_kernel");
 }
 extern "C" int msdr_biquad_q15_get_definition(msdr_biquad_q15 *S, uint32_t channel, int32_t definition[32])
@@ -882,8 +882,13 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     if (int rc = launch_check("chain_kernel")) return rc;
     if (e0) { HIP_TRY(hipEventRecord(e1, c->ctx->stream)); c->events.emplace_back(e0, e1); }
 
-    for (uint32_t k = 0; k < c->nnodes; k++)
-        if (int rc = msdr_biquad_q15_update(c->nodes[k], (q15_t *)d_audio, (uint32_t)n_samples)) return rc;
+    if (c->nnodes == 2) {      // biquad1_dac -> biquad2_dac in one pass over the audio
+        hipLaunchKernelGGL((biquad_teensy_kernel<2>), dim3((c->channels + 63) / 64), dim3(64), 0, c->ctx->stream, (short *)d_audio,
+                           c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);
+        if (int rc = launch_check("biquad_teensy_kernel<2>")) return rc;
+    } else if (c->nnodes == 1) {
+        if (int rc = msdr_biquad_q15_update(c->nodes[0], (q15_t *)d_audio, (uint32_t)n_samples)) return rc;
+    }
 
     hipLaunchKernelGGL((history_kernel<int16_t>), dim3(grid_1d((long long)c->channels * c->hist_len)), dim3(256), 0, c->ctx->stream,
                        d_if, (const int16_t *)c->d_hist[c->cur], c->d_hist[c->cur ^ 1], (long long)n_samples, (int)c->hist_len,

@@ -5,6 +5,7 @@
 #include "../../include/msdr.h"
 #include "msdr_kernels.hiph"
 #include "msdr_chain_fold.hiph"
+#include "msdr_chain_fft.hiph"
 #include "msdr_design.h"
 
 #include <algorithm>
@@ -623,6 +624,11 @@ struct msdr_chain {
     int *d_fset;                      // [channels]
     BiquadCascadeTables<kFoldR> *d_bq_fold;
     std::vector<int> h_mode, h_tapset;
+    // overlap-save FFT path (msdr_chain_fft.hiph)
+    int fft_LP;                       // 0 = not eligible; else outputs per lane (15: N <= 257, 14: N <= 513)
+    std::vector<char> fft_am_ok;      // per tap set: AM may use the FFT path (both branches share the taps)
+    float *d_fft_h, *d_fft_tw;
+    void *d_bq_fft;
     msdr_biquad_q15 *nodes[2];
     msdr_chain_info info;
     // optional per-launch timing of the main kernel
@@ -638,6 +644,7 @@ static void chain_free(msdr_chain *c)
     hipFree(c->d_taps); hipFree(c->d_osc); hipFree(c->d_mode); hipFree(c->d_tapset);
     hipFree(c->d_hist[0]); hipFree(c->d_hist[1]); hipFree(c->d_bq); hipFree(c->d_bq_state);
     hipFree(c->d_ftaps); hipFree(c->d_fset); hipFree(c->d_bq_fold);
+    hipFree(c->d_fft_h); hipFree(c->d_fft_tw); hipFree(c->d_bq_fft);
     for (int k = 0; k < 2; k++) if (c->nodes[k]) msdr_biquad_q15_destroy(c->nodes[k]);
     for (auto &e : c->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete c;
@@ -674,6 +681,13 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->ctx = ctx; c->arith = cfg->arith; c->mixer = cfg->mixer; c->sqrt_kind = cfg->sqrt_kind;
     c->channels = cfg->channels; c->ntaps = cfg->num_taps; c->ntaps_pad = (cfg->num_taps + 3u) & ~3u;
     c->hist_len = c->ntaps_pad - 1; c->tapsets = cfg->num_tapsets;
+    c->fft_LP = 0;
+    // measured crossover on MI355X: the FFT kernel's cost does not depend on N, the sliding dot product's
+    // grows by ~0.02 ms per tap per 2^30 samples; they meet near 250 taps
+    if (f32 && !(cfg->flags & MSDR_CHAIN_NO_FFT) && cfg->num_taps >= 248 && cfg->num_taps <= 513) {
+        c->fft_LP = (cfg->num_taps <= 257) ? 15 : 14;
+        c->hist_len = std::max<uint32_t>(c->hist_len, (uint32_t)(kFftF - kThreads * c->fft_LP));   // the FFT block's history
+    }
     c->osc_len = (cfg->mixer == MSDR_MIXER_NCO) ? cfg->osc_len : 4;
     c->in_scale = (cfg->in_scale == 0.0f) ? 1.0f / 32768.0f : cfg->in_scale;
     c->nstages = f32 ? cfg->num_biquad_stages : 0;
@@ -709,6 +723,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
             std::vector<float> o((size_t)c->osc_len * 2, 0.0f);
             if (cfg->mixer == MSDR_MIXER_NCO)
                 for (uint32_t k = 0; k < c->osc_len; k++) { o[2 * k] = ((const float *)cfg->osc_q)[k]; o[2 * k + 1] = ((const float *)cfg->osc_i)[k]; }
+            else { const float c4[4] = {1, 0, -1, 0}, s4[4] = {0, 1, 0, -1}; for (int k = 0; k < 4; k++) { o[2 * k] = c4[k]; o[2 * k + 1] = s4[k]; } }
             rc = upload(ctx, o, (float **)&c->d_osc);
         } else {
             std::vector<int32_t> o((size_t)c->osc_len * 2, 0);
@@ -792,13 +807,78 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                 make_cascade_tables<kFoldR>(cfg->biquad_coeffs, (int)c->nstages, &tabs[0]);
                 rc = upload(ctx, tabs, &c->d_bq_fold);
             }
-            if (!rc) {
-                std::vector<int> fs(c->channels);
-                for (uint32_t ch = 0; ch < c->channels; ch++) {
-                    const int m = c->h_mode[ch];
-                    fs[ch] = c->h_tapset[ch] * 3 + (m == MSDR_MODE_LSB ? 0 : m == MSDR_MODE_USB ? 1 : 2);
+        }
+    }
+    if (!rc && f32 && !c->d_fset) {       // per-channel table-set index (tap set x {LSB, USB, AM}), shared by the folded and FFT kernels
+        std::vector<int> fs(c->channels);
+        for (uint32_t ch = 0; ch < c->channels; ch++) {
+            const int m = c->h_mode[ch];
+            fs[ch] = c->h_tapset[ch] * 3 + (m == MSDR_MODE_LSB ? 0 : m == MSDR_MODE_USB ? 1 : 2);
+        }
+        rc = upload(ctx, fs, &c->d_fset);
+    }
+    if (!rc && c->fft_LP) {
+        // H[set*3+v] = FFT_4096(g) * in_scale / 4096,  g[j] = G[N-1-j] (plain convolution order),
+        // G = hI + j hQ (LSB), hI - j hQ (USB), hI (AM; only meaningful when hI == hQ)
+        const int F = kFftF;
+        std::vector<float> Hh((size_t)c->tapsets * 3 * F * 2, 0.0f);
+        std::vector<std::complex<double>> a(F);
+        c->fft_am_ok.assign(c->tapsets, 1);
+        for (uint32_t s = 0; s < c->tapsets; s++) {
+            const float *hi = (const float *)cfg->coeffs_i[s], *hq = (const float *)cfg->coeffs_q[s];
+            for (uint32_t k = 0; k < c->ntaps; k++) if (hi[k] != hq[k]) c->fft_am_ok[s] = 0;
+            for (int v = 0; v < 3; v++) {
+                std::fill(a.begin(), a.end(), std::complex<double>(0, 0));
+                for (uint32_t j = 0; j < c->ntaps; j++) {
+                    const uint32_t k = c->ntaps - 1 - j;
+                    a[j] = (v == 0) ? std::complex<double>(hi[k], hq[k]) : (v == 1) ? std::complex<double>(hi[k], -(double)hq[k])
+                                                                                     : std::complex<double>(hi[k], 0.0);
                 }
-                rc = upload(ctx, fs, &c->d_fset);
+                // iterative radix-2 DIT FFT in double
+                for (int i = 1, j = 0; i < F; i++) {
+                    int bit = F >> 1;
+                    for (; j & bit; bit >>= 1) j ^= bit;
+                    j ^= bit;
+                    if (i < j) std::swap(a[i], a[j]);
+                }
+                for (int len = 2; len <= F; len <<= 1) {
+                    const double ang = -2.0 * 3.14159265358979323846 / len;
+                    for (int i = 0; i < F; i += len)
+                        for (int k = 0; k < len / 2; k++) {
+                            const std::complex<double> w(std::cos(ang * k), std::sin(ang * k));
+                            const std::complex<double> u = a[i + k], t = a[i + k + len / 2] * w;
+                            a[i + k] = u + t; a[i + k + len / 2] = u - t;
+                        }
+                }
+                const double sc = (double)c->in_scale / F;
+                float *dst = Hh.data() + ((size_t)s * 3 + v) * F * 2;
+                for (int k = 0; k < F; k++) { dst[2 * k] = (float)(a[k].real() * sc); dst[2 * k + 1] = (float)(a[k].imag() * sc); }
+            }
+        }
+        rc = upload(ctx, Hh, &c->d_fft_h);
+        if (!rc) {
+            std::vector<float> tw((size_t)(256 + 4096) * 2);
+            for (int m = 0; m < 16; m++)
+                for (int k = 0; k < 16; k++) {
+                    const double ang = -2.0 * 3.14159265358979323846 * k * m / 256.0;
+                    tw[(m * 16 + k) * 2] = (float)std::cos(ang); tw[(m * 16 + k) * 2 + 1] = (float)std::sin(ang);
+                }
+            for (int m = 0; m < 16; m++)
+                for (int k = 0; k < 256; k++) {
+                    const double ang = -2.0 * 3.14159265358979323846 * k * m / 4096.0;
+                    tw[(256 + m * 256 + k) * 2] = (float)std::cos(ang); tw[(256 + m * 256 + k) * 2 + 1] = (float)std::sin(ang);
+                }
+            rc = upload(ctx, tw, &c->d_fft_tw);
+        }
+        if (!rc) {
+            if (c->fft_LP == 15) {
+                std::vector<BiquadCascadeTables<15>> tabs(1);
+                make_cascade_tables<15>(cfg->biquad_coeffs, (int)c->nstages, &tabs[0]);
+                rc = upload(ctx, tabs, (BiquadCascadeTables<15> **)&c->d_bq_fft);
+            } else {
+                std::vector<BiquadCascadeTables<14>> tabs(1);
+                make_cascade_tables<14>(cfg->biquad_coeffs, (int)c->nstages, &tabs[0]);
+                rc = upload(ctx, tabs, (BiquadCascadeTables<14> **)&c->d_bq_fft);
             }
         }
     }
@@ -837,7 +917,15 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     bool use_fold = f32 && c->fold_P > 0;
     if (use_fold && !c->fold_fs4_exact)
         for (int m : c->h_mode) if (m != MSDR_MODE_LSB && m != MSDR_MODE_USB) { use_fold = false; break; }
-    const int kTile = use_fold ? kFoldTile : kChainTile;
+    bool use_fft = f32 && c->fft_LP > 0;
+    if (use_fft)
+        for (uint32_t ch = 0; ch < c->channels; ch++) {
+            const int m = c->h_mode[ch];
+            if (m != MSDR_MODE_LSB && m != MSDR_MODE_USB && !c->fft_am_ok[c->h_tapset[ch]]) { use_fft = false; break; }
+        }
+    if (use_fft) use_fold = false;
+    const int kTile = use_fft ? kThreads * c->fft_LP : use_fold ? kFoldTile : kChainTile;
+    p.fft_h = c->d_fft_h; p.fft_tw = c->d_fft_tw; p.bq_fft = c->d_bq_fft;
     p.ftaps = c->d_ftaps; p.chan_fset = c->d_fset; p.fold_period = c->fold_P; p.bq_fold = c->d_bq_fold;
     p.fold_rot = c->fold_P ? (int)(c->phase % c->fold_P) : 0;
 
@@ -866,7 +954,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     nseg = (tiles + seg_tiles - 1) / seg_tiles;
     p.nseg = (int)nseg; p.seg_len = seg_tiles * kTile; p.warm = (int)(nseg > 1 ? warm_tiles * kTile : 0);
 
-    const size_t lds = use_fold ? fold_lds_bytes(p.ntaps_pad) : chain_lds_bytes(p.ntaps_pad);
+    const size_t lds = use_fft ? fft_lds_bytes() : use_fold ? fold_lds_bytes(p.ntaps_pad) : chain_lds_bytes(p.ntaps_pad);
     const unsigned grid = (unsigned)(c->channels * nseg);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && c->events.size() < 8192) {
@@ -874,7 +962,9 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         HIP_TRY(hipEventRecord(e0, c->ctx->stream));
     }
     const char *kname = f32 ? "chain_kernel<ArithF32>" : "chain_kernel<ArithQ15>";
-    if (use_fold && c->fold_P == 4) { hipLaunchKernelGGL((chain_fold_kernel<4>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<4>"; }
+    if (use_fft && c->fft_LP == 15) { hipLaunchKernelGGL((chain_fft_kernel<15>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fft_kernel<15>"; }
+    else if (use_fft) { hipLaunchKernelGGL((chain_fft_kernel<14>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fft_kernel<14>"; }
+    else if (use_fold && c->fold_P == 4) { hipLaunchKernelGGL((chain_fold_kernel<4>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<4>"; }
     else if (use_fold && c->fold_P == 2) { hipLaunchKernelGGL((chain_fold_kernel<2>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<2>"; }
     else if (use_fold) { hipLaunchKernelGGL((chain_fold_kernel<1>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<1>"; }
     else if (f32) hipLaunchKernelGGL((chain_kernel<ArithF32>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p);

@@ -19,6 +19,7 @@ BQ_LOWPASS, BQ_HIGHPASS, BQ_BANDPASS, BQ_NOTCH, BQ_LOWSHELF, BQ_HIGHSHELF = rang
 AUDIO_SAMPLE_RATE_EXACT = 44117.64706
 MAX_TAPSETS = 8
 CHAIN_NO_TAP_FOLDING = 1
+CHAIN_NO_FFT = 4
 
 STATUS_ARGUMENT_ERROR, STATUS_LENGTH_ERROR, STATUS_NO_DEVICE = -1, -2, -100
 

@@ -298,3 +298,62 @@ def test_chain_f32_am_with_non_fs4_nco_uses_general_kernel(ctx, orc):
     assert chain.info()["kernel"] == "chain_kernel<ArithF32>"
     for c, m in enumerate((orclib.AM, orclib.LSB)):
         assert rel_rms(got[c], orc.chain_f32(x[c], m, hi, hq, oi, oq, None)) < TOL
+
+
+# ---------------------------------------------------------------- fp32, overlap-save FFT kernel ---
+@pytest.mark.parametrize("ntaps", [248, 256, 257, 300, 512, 513])
+@pytest.mark.parametrize("mode", [orclib.LSB, orclib.USB, orclib.AM])
+def test_chain_f32_fft_kernel_vs_oracle(ctx, orc, ntaps, mode):
+    """Long FIRs take the LDS-resident overlap-save FFT kernel; any oscillator table works there (here one
+    that is NOT short-periodic), AM needs both branches to share their taps."""
+    rng = np.random.default_rng(ntaps * 3 + mode)
+    if mode == orclib.AM:
+        hi = (np.sinc(2 * 2800 / 24000 * (np.arange(ntaps) - (ntaps - 1) / 2)) * np.kaiser(ntaps, 7.0)).astype(np.float32)
+        hi /= hi.sum()
+        hq = hi
+    else:
+        hi, hq = _hilbert_pair(ntaps)
+    oi, oq = _nco(128, 5)                                   # 5 cycles per 128 samples: period 128
+    bq = _f32_biquads(orc, 2)
+    x = rng.integers(-8000, 8001, (3, 20011)).astype(np.int16)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 3, hi, hq, mixer=msdr.MIXER_NCO, mode=mode, osc_i=oi, osc_q=oq, biquad_coeffs=bq)
+    for block in (None, 4999, 128):
+        chain.reset()
+        got = run_chain(ctx, chain, x, np.float32, block)
+        assert chain.info()["kernel"] == "chain_fft_kernel<%d>" % (15 if ntaps <= 257 else 14), chain.info()
+        for c in range(3):
+            want = orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq)
+            assert rel_rms(got[c], want) < TOL, (block, c, rel_rms(got[c], want))
+    plain = msdr.Chain(ctx, msdr.ARITH_F32, 3, hi, hq, mixer=msdr.MIXER_NCO, mode=mode, osc_i=oi, osc_q=oq, biquad_coeffs=bq,
+                       flags=msdr.CHAIN_NO_FFT)
+    got2 = run_chain(ctx, plain, x, np.float32)
+    assert not plain.info()["kernel"].startswith("chain_fft")
+    for c in range(3):
+        assert rel_rms(got2[c], orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq)) < TOL
+
+
+def test_chain_f32_fft_am_with_distinct_branches_falls_back(ctx, orc):
+    rng = np.random.default_rng(5)
+    hi, hq = _hilbert_pair(256)
+    x = rng.integers(-8000, 8001, (2, 6000)).astype(np.int16)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 2, hi, hq, mixer=msdr.MIXER_FS4, mode=orclib.CW)
+    got = run_chain(ctx, chain, x, np.float32)
+    assert chain.info()["kernel"] == "chain_fold_kernel<4>"
+    cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+    for c in range(2):
+        assert rel_rms(got[c], orc.chain_f32(x[c], orclib.CW, hi, hq, sin4, cos4, None)) < TOL
+
+
+def test_chain_f32_fft_time_segments_long_stream(ctx, orc):
+    rng = np.random.default_rng(6)
+    n = 1 << 20
+    x = rng.integers(-8000, 8001, (1, n)).astype(np.int16)
+    hi, hq = _hilbert_pair(256)
+    oi, oq = _q15_nco(4, 1)
+    bq = _f32_biquads(orc, 2)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 1, hi, hq, mixer=msdr.MIXER_NCO, mode=orclib.LSB, osc_i=oi, osc_q=oq, biquad_coeffs=bq)
+    got = run_chain(ctx, chain, x, np.float32)
+    info = chain.info()
+    assert info["kernel"] == "chain_fft_kernel<15>" and info["time_segments"] > 1
+    want = orc.chain_f32(x[0], orclib.LSB, hi, hq, oi, oq, bq)
+    assert rel_rms(got[0], want) < TOL

@@ -352,6 +352,9 @@ def main():
     flop_written = 4.0 * wl["taps"] + extra                      # as the reference writes it: two N-tap FIRs
     folded = info["kernel"].startswith("chain_fold")
     flop_exec = (2.0 if folded else 4.0) * info["taps_padded"] + extra     # what the kernel executes (tap folding halves the MACs)
+    if info["kernel"].startswith("chain_fft"):                             # overlap-save: 2 complex 4096-point FFTs (5 F log2 F each) + pointwise
+        F = 4096.0                                                         # product (6 F) + mixer (2 F) per block of `tile` outputs
+        flop_exec = (2 * 5 * F * 12 + 8 * F) / info["tile"] + 4 + 9 * len(wl["bq"])
     out = {
         "metric": "Msamples/s through IF->I/Q->FIR->demod->IIR chain; achieved HBM GB/s vs peak",
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -217,6 +217,8 @@ def main():
     ap.add_argument("--channels", type=int, default=0, help="override channels per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-fold", action="store_true", help="keep mixer and FIR as separate arithmetic steps")
+    ap.add_argument("--no-fft", action="store_true", help="never use the overlap-save FFT kernel")
+    ap.add_argument("--no-mfma", action="store_true", help="keep the folded FIR on the fp32 VALU (no split-fp16 matrix-core kernel)")
     ap.add_argument("--time-segments", type=int, default=0)
     ap.add_argument("--arith", default="f32", choices=["f32", "q15"],
                     help="f32 = the north-star flavour (default); q15 = the reference as written (int16 out, bit-exact)")
@@ -286,7 +288,8 @@ def main():
         chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, wl["ci"], wl["cq"], mixer=wl["mixer"], mode=wl["mode"], modes=wl["modes"],
                            tapsets=wl["tapsets"], osc_i=wl["osc"][0] if wl["osc"] else None, osc_q=wl["osc"][1] if wl["osc"] else None,
                            biquad_coeffs=wl["bq"] if len(wl["bq"]) else None, time_segments=args.time_segments,
-                           flags=msdr.CHAIN_NO_TAP_FOLDING if args.no_fold else 0)
+                           flags=(msdr.CHAIN_NO_TAP_FOLDING if args.no_fold else 0) | (msdr.CHAIN_NO_FFT if args.no_fft else 0)
+                           | (msdr.CHAIN_NO_MFMA if args.no_mfma else 0))
     x = synth_if(torch, dev, ch, n, wl["seed"])
     y = torch.empty((ch, n), dtype=torch.int16 if q15 else torch.float32, device=dev)
     torch.cuda.synchronize(dev)

@@ -208,6 +208,7 @@ typedef struct {
 } msdr_chain_config;
 #define MSDR_CHAIN_NO_TAP_FOLDING 1u /* F32: keep mixer and FIR pair as separate arithmetic steps (as written) */
 #define MSDR_CHAIN_NO_FFT 4u         /* F32: never use the overlap-save FFT kernel (long FIRs stay sliding dot products) */
+#define MSDR_CHAIN_NO_MFMA 8u        /* F32: never run the folded FIR on the matrix cores (split-fp16 MFMA kernel) */
 
 typedef struct msdr_chain msdr_chain;
 int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_chain **out);

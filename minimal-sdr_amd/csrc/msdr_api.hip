@@ -6,6 +6,7 @@
 #include "msdr_kernels.hiph"
 #include "msdr_chain_fold.hiph"
 #include "msdr_chain_fft.hiph"
+#include "msdr_chain_mfma.hiph"
 #include "msdr_design.h"
 
 #include <algorithm>
@@ -629,6 +630,11 @@ struct msdr_chain {
     std::vector<char> fft_am_ok;      // per tap set: AM may use the FFT path (both branches share the taps)
     float *d_fft_h, *d_fft_tw;
     void *d_bq_fft;
+    // matrix-core path (msdr_chain_mfma.hiph): any short-period oscillator, any mode
+    bool mf_ok;
+    int mf_halo, mf_bsteps, mf_stride;
+    char *d_mf_tab;
+    BiquadCascadeTables<kMfL> *d_bq_mf;
     msdr_biquad_q15 *nodes[2];
     msdr_chain_info info;
     // optional per-launch timing of the main kernel
@@ -644,7 +650,7 @@ static void chain_free(msdr_chain *c)
     hipFree(c->d_taps); hipFree(c->d_osc); hipFree(c->d_mode); hipFree(c->d_tapset);
     hipFree(c->d_hist[0]); hipFree(c->d_hist[1]); hipFree(c->d_bq); hipFree(c->d_bq_state);
     hipFree(c->d_ftaps); hipFree(c->d_fset); hipFree(c->d_bq_fold);
-    hipFree(c->d_fft_h); hipFree(c->d_fft_tw); hipFree(c->d_bq_fft);
+    hipFree(c->d_fft_h); hipFree(c->d_fft_tw); hipFree(c->d_bq_fft); hipFree(c->d_mf_tab); hipFree(c->d_bq_mf);
     for (int k = 0; k < 2; k++) if (c->nodes[k]) msdr_biquad_q15_destroy(c->nodes[k]);
     for (auto &e : c->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete c;
@@ -688,6 +694,8 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         c->fft_LP = (cfg->num_taps <= 257) ? 15 : 14;
         c->hist_len = std::max<uint32_t>(c->hist_len, (uint32_t)(kFftF - kThreads * c->fft_LP));   // the FFT block's history
     }
+    if (f32 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && mf_halo((int)cfg->num_taps) <= 2048)      // the matrix-core kernel's window halo
+        c->hist_len = std::max<uint32_t>(c->hist_len, (uint32_t)mf_halo((int)cfg->num_taps));
     c->osc_len = (cfg->mixer == MSDR_MIXER_NCO) ? cfg->osc_len : 4;
     c->in_scale = (cfg->in_scale == 0.0f) ? 1.0f / 32768.0f : cfg->in_scale;
     c->nstages = f32 ? cfg->num_biquad_stages : 0;
@@ -809,6 +817,87 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
             }
         }
     }
+    // ---- matrix-core tables (F32, short-period oscillator): B fragments per (tap set x {LSB, USB, envelope}, rotation) ----
+    c->mf_ok = false;
+    if (!rc && f32 && c->fold_P > 0 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && mf_halo((int)c->ntaps) <= 2048) {
+        const int P = c->fold_P, N = (int)c->ntaps, H = mf_halo(N), J = H / 32 + 1, KI = H + 32;
+        std::vector<double> oc(P), os(P);
+        if (cfg->mixer == MSDR_MIXER_FS4) { const double c4[4] = {1, 0, -1, 0}, s4[4] = {0, 1, 0, -1}; for (int k = 0; k < 4; k++) { oc[k] = c4[k]; os[k] = s4[k]; } }
+        else for (int k = 0; k < P; k++) { oc[k] = ((const float *)cfg->osc_q)[k]; os[k] = ((const float *)cfg->osc_i)[k]; }
+        struct Tab { MfmaTableHeader h; std::vector<_Float16> frags; };
+        std::vector<Tab> tabs((size_t)c->tapsets * 3 * P);
+        int bsteps = 0;
+        bool ok = true;
+        std::vector<double> M[2];
+        M[0].resize((size_t)KI * 32); M[1].resize((size_t)KI * 32);
+        for (uint32_t s = 0; s < c->tapsets && ok; s++) {
+            const float *hi = (const float *)cfg->coeffs_i[s], *hq = (const float *)cfg->coeffs_q[s];
+            for (int v = 0; v < 3 && ok; v++)
+                for (int rot = 0; rot < P && ok; rot++) {
+                    // B[i][b]: window sample i (oscillator phase (rot + i) mod P) meets output column b at delay H + b - i,
+                    // i.e. coefficient index N - 1 - delay (arm_fir keeps its coefficients time-reversed)
+                    double maxabs = 0.0;
+                    for (int i = 0; i < KI; i++)
+                        for (int b = 0; b < 32; b++) {
+                            const int delay = H + b - i;
+                            double m0 = 0.0, m1 = 0.0;
+                            if (delay >= 0 && delay < N) {
+                                const int k = N - 1 - delay, psi = (rot + i) % P;
+                                if (v == 2) { m0 = (double)hi[k] * oc[psi]; m1 = (double)hq[k] * os[psi]; }
+                                else m0 = (double)hi[k] * oc[psi] + (v == 0 ? -1.0 : 1.0) * (double)hq[k] * os[psi];
+                            }
+                            M[0][(size_t)i * 32 + b] = m0; M[1][(size_t)i * 32 + b] = m1;
+                            maxabs = std::max(maxabs, std::max(std::fabs(m0), std::fabs(m1)));
+                        }
+                    int ex = 0;
+                    if (maxabs > 0) { std::frexp(maxabs, &ex); ex = 14 - ex; }           // maxabs * 2^ex in [2^13, 2^14)
+                    const double scale = std::ldexp(1.0, ex);
+                    Tab &T = tabs[((size_t)s * 3 + v) * P + rot];
+                    memset(&T.h, 0, sizeof T.h);
+                    T.h.am = (v == 2); T.h.post = (float)((double)c->in_scale / scale);
+                    int ns = 0;
+                    for (int o = 0; o < (v == 2 ? 2 : 1); o++) {
+                        for (int src = 0; src < 2; src++)
+                            for (int j = 0; j < J; j++) {
+                                bool any = false;
+                                for (int m = 0; m < 16 && !any; m++)
+                                    for (int b = 0; b < 32 && !any; b++) any = M[o][(size_t)(2 * (16 * j + m) + src) * 32 + b] != 0.0;
+                                if (!any) continue;
+                                if (ns >= kMfMaxSteps) { ok = false; break; }
+                                T.h.desc[ns++] = (src << 16) | j;
+                                const size_t base = T.frags.size();
+                                T.frags.resize(base + 1024);                          // hi piece [64 lanes][8], then lo piece
+                                for (int l = 0; l < 64; l++)
+                                    for (int jj = 0; jj < 8; jj++) {
+                                        const double val = M[o][(size_t)(2 * (16 * j + 8 * (l >> 5) + jj) + src) * 32 + (l & 31)] * scale;
+                                        const _Float16 vh = (_Float16)val;
+                                        T.frags[base + l * 8 + jj] = vh;
+                                        T.frags[base + 512 + l * 8 + jj] = (_Float16)(val - (double)vh);
+                                    }
+                            }
+                        if (o == 0) T.h.n0 = ns; else T.h.n1 = ns - T.h.n0;
+                    }
+                    bsteps = std::max(bsteps, ns);
+                }
+        }
+        if (ok && bsteps > 0 && mf_lds_bytes(H, bsteps) <= 160 * 1024) {
+            const int stride = kMfHdrBytes + bsteps * 2048;
+            std::vector<char> blob((size_t)stride * tabs.size(), 0);
+            for (size_t t = 0; t < tabs.size(); t++) {
+                memcpy(blob.data() + t * stride, &tabs[t].h, sizeof(MfmaTableHeader));
+                memcpy(blob.data() + t * stride + kMfHdrBytes, tabs[t].frags.data(), tabs[t].frags.size() * sizeof(_Float16));
+            }
+            rc = upload(ctx, blob, &c->d_mf_tab);
+            if (!rc) {
+                std::vector<BiquadCascadeTables<kMfL>> bt(1);
+                make_cascade_tables<kMfL>(cfg->biquad_coeffs, (int)c->nstages, &bt[0]);
+                rc = upload(ctx, bt, &c->d_bq_mf);
+            }
+            if (!rc) {
+                c->mf_ok = true; c->mf_halo = H; c->mf_bsteps = bsteps; c->mf_stride = stride;
+            }
+        }
+    }
     if (!rc && f32 && !c->d_fset) {       // per-channel table-set index (tap set x {LSB, USB, AM}), shared by the folded and FFT kernels
         std::vector<int> fs(c->channels);
         for (uint32_t ch = 0; ch < c->channels; ch++) {
@@ -923,8 +1012,11 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             const int m = c->h_mode[ch];
             if (m != MSDR_MODE_LSB && m != MSDR_MODE_USB && !c->fft_am_ok[c->h_tapset[ch]]) { use_fft = false; break; }
         }
-    if (use_fft) use_fold = false;
-    const int kTile = use_fft ? kThreads * c->fft_LP : use_fold ? kFoldTile : kChainTile;
+    const bool use_mf = f32 && c->mf_ok;
+    if (use_mf) use_fft = false;
+    if (use_fft || use_mf) use_fold = false;
+    const int kTile = use_mf ? kMfTile : use_fft ? kThreads * c->fft_LP : use_fold ? kFoldTile : kChainTile;
+    p.mf_tab = c->d_mf_tab; p.mf_stride = c->mf_stride; p.mf_halo = c->mf_halo; p.mf_bsteps = c->mf_bsteps; p.bq_mf = c->d_bq_mf;
     p.fft_h = c->d_fft_h; p.fft_tw = c->d_fft_tw; p.bq_fft = c->d_bq_fft;
     p.ftaps = c->d_ftaps; p.chan_fset = c->d_fset; p.fold_period = c->fold_P; p.bq_fold = c->d_bq_fold;
     p.fold_rot = c->fold_P ? (int)(c->phase % c->fold_P) : 0;
@@ -954,7 +1046,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     nseg = (tiles + seg_tiles - 1) / seg_tiles;
     p.nseg = (int)nseg; p.seg_len = seg_tiles * kTile; p.warm = (int)(nseg > 1 ? warm_tiles * kTile : 0);
 
-    const size_t lds = use_fft ? fft_lds_bytes() : use_fold ? fold_lds_bytes(p.ntaps_pad) : chain_lds_bytes(p.ntaps_pad);
+    const size_t lds = use_mf ? mf_lds_bytes(c->mf_halo, c->mf_bsteps) : use_fft ? fft_lds_bytes() : use_fold ? fold_lds_bytes(p.ntaps_pad) : chain_lds_bytes(p.ntaps_pad);
     const unsigned grid = (unsigned)(c->channels * nseg);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && c->events.size() < 8192) {
@@ -962,7 +1054,8 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         HIP_TRY(hipEventRecord(e0, c->ctx->stream));
     }
     const char *kname = f32 ? "chain_kernel<ArithF32>" : "chain_kernel<ArithQ15>";
-    if (use_fft && c->fft_LP == 15) { hipLaunchKernelGGL((chain_fft_kernel<15>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fft_kernel<15>"; }
+    if (use_mf) { hipLaunchKernelGGL(chain_mfma_kernel, dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_mfma_kernel"; }
+    else if (use_fft && c->fft_LP == 15) { hipLaunchKernelGGL((chain_fft_kernel<15>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fft_kernel<15>"; }
     else if (use_fft) { hipLaunchKernelGGL((chain_fft_kernel<14>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fft_kernel<14>"; }
     else if (use_fold && c->fold_P == 4) { hipLaunchKernelGGL((chain_fold_kernel<4>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<4>"; }
     else if (use_fold && c->fold_P == 2) { hipLaunchKernelGGL((chain_fold_kernel<2>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<2>"; }

@@ -82,6 +82,12 @@ struct ChainParams {
     const float *fft_h;        // [hsets][4096] complex frequency responses (1/4096 and in_scale folded in)
     const float *fft_tw;       // complex twiddles: [16][16] W_256^(k m) then [16][256] W_4096^(k m)
     const void *bq_fft;        // BiquadCascadeTables<LP> for the kernel's LP
+    // matrix-core kernel (msdr_chain_mfma.hiph); uses chan_fset, fold_period, fold_rot
+    const void *mf_tab;        // [fsets][P rotations] tables: MfmaTableHeader (1 KB) + B fragments, mf_stride bytes apart
+    int mf_stride;
+    int mf_halo;               // H: window samples before the tile, a multiple of 32 >= ntaps - 1
+    int mf_bsteps;             // k-steps the LDS B region holds (max n0 + n1 over the tables)
+    const void *bq_mf;         // BiquadCascadeTables<16>
 };
 
 }  // namespace msdr

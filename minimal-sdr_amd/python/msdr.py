@@ -20,6 +20,7 @@ AUDIO_SAMPLE_RATE_EXACT = 44117.64706
 MAX_TAPSETS = 8
 CHAIN_NO_TAP_FOLDING = 1
 CHAIN_NO_FFT = 4
+CHAIN_NO_MFMA = 8
 
 STATUS_ARGUMENT_ERROR, STATUS_LENGTH_ERROR, STATUS_NO_DEVICE = -1, -2, -100
 

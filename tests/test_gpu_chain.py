@@ -242,20 +242,26 @@ def _q15_nco(p, cycles, length=128):
     return (s / 32768.0).astype(np.float32), (c / 32768.0).astype(np.float32)
 
 
+ENGINES = {"mfma": 0, "valu": msdr.CHAIN_NO_MFMA}      # folded FIR on the matrix cores / on the fp32 VALU
+
+
+@pytest.mark.parametrize("engine", ["mfma", "valu"])
 @pytest.mark.parametrize("period", [1, 2, 4])
 @pytest.mark.parametrize("block", [None, 333, 128, 3073])
 @pytest.mark.parametrize("mode", [orclib.LSB, orclib.USB])
-def test_chain_f32_folded_ssb_vs_oracle(ctx, orc, period, block, mode):
-    """Short-period oscillators take the folded kernel (mixer folded into the taps).  Odd block
-    lengths rotate the oscillator phase between calls and misalign the rows of channels > 0."""
+def test_chain_f32_folded_ssb_vs_oracle(ctx, orc, period, block, mode, engine):
+    """Short-period oscillators take a folded kernel (mixer folded into the taps): the split-fp16 matrix-core
+    kernel, or with MSDR_CHAIN_NO_MFMA the packed-fp32 one.  Odd block lengths rotate the oscillator phase
+    between calls and misalign the rows of channels > 0."""
     rng = np.random.default_rng(100 + period)
     hi, hq = _hilbert_pair(100)
     oi, oq = _q15_nco(period, 1)
     bq = _f32_biquads(orc, 2)
     x = rng.integers(-8000, 8001, (3, 7001)).astype(np.int16)
-    chain = msdr.Chain(ctx, msdr.ARITH_F32, 3, hi, hq, mixer=msdr.MIXER_NCO, mode=mode, osc_i=oi, osc_q=oq, biquad_coeffs=bq)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 3, hi, hq, mixer=msdr.MIXER_NCO, mode=mode, osc_i=oi, osc_q=oq, biquad_coeffs=bq,
+                       flags=ENGINES[engine])
     got = run_chain(ctx, chain, x, np.float32, block)
-    assert chain.info()["kernel"] == "chain_fold_kernel<%d>" % period
+    assert chain.info()["kernel"] == ("chain_mfma_kernel" if engine == "mfma" else "chain_fold_kernel<%d>" % period)
     for c in range(3):
         want = orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq)
         assert rel_rms(got[c], want) < TOL, (c, rel_rms(got[c], want))
@@ -268,8 +274,9 @@ def test_chain_f32_folded_ssb_vs_oracle(ctx, orc, period, block, mode):
         assert rel_rms(got2[c], orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq)) < TOL
 
 
+@pytest.mark.parametrize("engine", ["mfma", "valu"])
 @pytest.mark.parametrize("block", [None, 129, 1000])
-def test_chain_f32_folded_am_fs4_odd_blocks(ctx, orc, block):
+def test_chain_f32_folded_am_fs4_odd_blocks(ctx, orc, block, engine):
     """AM through the folded kernel (Fs/4 zero skipping) with block lengths that leave the mixer at
     every phase 0..3 at a call boundary."""
     rng = np.random.default_rng(77)
@@ -277,25 +284,26 @@ def test_chain_f32_folded_am_fs4_odd_blocks(ctx, orc, block):
     lp /= lp.sum()
     x = rng.integers(-8000, 8001, (2, 5003)).astype(np.int16)
     bq = _f32_biquads(orc, 1)
-    chain = msdr.Chain(ctx, msdr.ARITH_F32, 2, lp, lp, mixer=msdr.MIXER_FS4, mode=orclib.AM, biquad_coeffs=bq)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 2, lp, lp, mixer=msdr.MIXER_FS4, mode=orclib.AM, biquad_coeffs=bq, flags=ENGINES[engine])
     got = run_chain(ctx, chain, x, np.float32, block)
-    assert chain.info()["kernel"] == "chain_fold_kernel<4>"
+    assert chain.info()["kernel"] == ("chain_mfma_kernel" if engine == "mfma" else "chain_fold_kernel<4>")
     cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
     for c in range(2):
         assert rel_rms(got[c], orc.chain_f32(x[c], orclib.AM, lp, lp, sin4, cos4, bq)) < TOL
 
 
-def test_chain_f32_am_with_non_fs4_nco_uses_general_kernel(ctx, orc):
-    """AM can only be folded for the exact Fs/4 pattern; a q15-rounded fs/4 table (0.99997) must fall
-    back to the as-written kernel and still match."""
+@pytest.mark.parametrize("engine", ["mfma", "valu"])
+def test_chain_f32_am_with_non_fs4_nco(ctx, orc, engine):
+    """The packed-fp32 folded kernel does AM only for the exact Fs/4 pattern: a q15-rounded fs/4 table (0.99997)
+    falls back to the as-written kernel there.  The matrix-core kernel takes any short-period table."""
     rng = np.random.default_rng(78)
     hi, hq = _hilbert_pair(100)
     oi, oq = _q15_nco(4, 1)
     x = rng.integers(-8000, 8001, (2, 4000)).astype(np.int16)
     chain = msdr.Chain(ctx, msdr.ARITH_F32, 2, hi, hq, mixer=msdr.MIXER_NCO, modes=np.array([orclib.AM, orclib.LSB], np.int32),
-                       osc_i=oi, osc_q=oq)
+                       osc_i=oi, osc_q=oq, flags=ENGINES[engine])
     got = run_chain(ctx, chain, x, np.float32)
-    assert chain.info()["kernel"] == "chain_kernel<ArithF32>"
+    assert chain.info()["kernel"] == ("chain_mfma_kernel" if engine == "mfma" else "chain_kernel<ArithF32>")
     for c, m in enumerate((orclib.AM, orclib.LSB)):
         assert rel_rms(got[c], orc.chain_f32(x[c], m, hi, hq, oi, oq, None)) < TOL
 
@@ -336,7 +344,7 @@ def test_chain_f32_fft_am_with_distinct_branches_falls_back(ctx, orc):
     rng = np.random.default_rng(5)
     hi, hq = _hilbert_pair(256)
     x = rng.integers(-8000, 8001, (2, 6000)).astype(np.int16)
-    chain = msdr.Chain(ctx, msdr.ARITH_F32, 2, hi, hq, mixer=msdr.MIXER_FS4, mode=orclib.CW)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 2, hi, hq, mixer=msdr.MIXER_FS4, mode=orclib.CW, flags=msdr.CHAIN_NO_MFMA)
     got = run_chain(ctx, chain, x, np.float32)
     assert chain.info()["kernel"] == "chain_fold_kernel<4>"
     cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
@@ -344,16 +352,59 @@ def test_chain_f32_fft_am_with_distinct_branches_falls_back(ctx, orc):
         assert rel_rms(got[c], orc.chain_f32(x[c], orclib.CW, hi, hq, sin4, cos4, None)) < TOL
 
 
-def test_chain_f32_fft_time_segments_long_stream(ctx, orc):
+@pytest.mark.parametrize("engine", ["mfma", "valu"])
+def test_chain_f32_fft_time_segments_long_stream(ctx, orc, engine):
     rng = np.random.default_rng(6)
     n = 1 << 20
     x = rng.integers(-8000, 8001, (1, n)).astype(np.int16)
     hi, hq = _hilbert_pair(256)
     oi, oq = _q15_nco(4, 1)
     bq = _f32_biquads(orc, 2)
-    chain = msdr.Chain(ctx, msdr.ARITH_F32, 1, hi, hq, mixer=msdr.MIXER_NCO, mode=orclib.LSB, osc_i=oi, osc_q=oq, biquad_coeffs=bq)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 1, hi, hq, mixer=msdr.MIXER_NCO, mode=orclib.LSB, osc_i=oi, osc_q=oq, biquad_coeffs=bq,
+                       flags=ENGINES[engine])
     got = run_chain(ctx, chain, x, np.float32)
     info = chain.info()
-    assert info["kernel"] == "chain_fft_kernel<15>" and info["time_segments"] > 1
+    assert info["kernel"] == ("chain_mfma_kernel" if engine == "mfma" else "chain_fft_kernel<15>") and info["time_segments"] > 1
     want = orc.chain_f32(x[0], orclib.LSB, hi, hq, oi, oq, bq)
     assert rel_rms(got[0], want) < TOL
+
+
+# ---------------------------------------------------------------- fp32, matrix-core kernel ---------
+@pytest.mark.parametrize("ntaps", [1, 2, 31, 33, 64, 100, 129, 256, 512])
+@pytest.mark.parametrize("mode", [orclib.LSB, orclib.AM])
+def test_chain_f32_mfma_tap_counts(ctx, orc, ntaps, mode):
+    """The Toeplitz operand is built per tap count (halo = ntaps - 1 rounded up to 32); Fs/4 mixer, mixed block sizes,
+    three channels so that rows of channels > 0 are misaligned for odd n."""
+    rng = np.random.default_rng(900 + ntaps)
+    if ntaps < 8:
+        hi = rng.standard_normal(ntaps).astype(np.float32)
+        hq = rng.standard_normal(ntaps).astype(np.float32)
+    else:
+        hi, hq = _hilbert_pair(ntaps)
+    bq = _f32_biquads(orc, 2)
+    cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+    for n in (12288 + 8, 9001):
+        x = rng.integers(-32768, 32768, (3, n)).astype(np.int16)
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, 3, hi, hq, mixer=msdr.MIXER_FS4, mode=mode, biquad_coeffs=bq)
+        for block in (None, 4100):
+            chain.reset()
+            got = run_chain(ctx, chain, x, np.float32, block)
+            assert chain.info()["kernel"] == "chain_mfma_kernel", chain.info()
+            for c in range(3):
+                want = orc.chain_f32(x[c], mode, hi, hq, sin4, cos4, bq)
+                assert rel_rms(got[c], want) < TOL, (n, block, c, rel_rms(got[c], want))
+
+
+def test_chain_f32_mfma_weak_signal_keeps_fp32_accuracy(ctx, orc):
+    """The fp16 split of the samples is a FLOATING split (11 significant bits + exact remainder), so a weak signal
+    (|x| <= 40) is as accurate as a full-scale one; full-scale extremes (-32768, 32767) are exact too."""
+    rng = np.random.default_rng(31)
+    hi, hq = _hilbert_pair(100)
+    cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+    weak = rng.integers(-40, 41, (1, 8192)).astype(np.int16)
+    rail = rng.choice(np.array([-32768, 32767, -32767, 32766, 2049, -2049], np.int16), (1, 8192))
+    for x in (weak, rail):
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, 1, hi, hq, mixer=msdr.MIXER_FS4, mode=orclib.USB)
+        got = run_chain(ctx, chain, x, np.float32)
+        assert chain.info()["kernel"] == "chain_mfma_kernel"
+        assert rel_rms(got[0], orc.chain_f32(x[0], orclib.USB, hi, hq, sin4, cos4, None)) < 2e-6

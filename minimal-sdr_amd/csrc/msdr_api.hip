@@ -827,7 +827,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         struct Tab { MfmaTableHeader h; std::vector<_Float16> frags; };
         std::vector<Tab> tabs((size_t)c->tapsets * 3 * P);
         int bsteps = 0;
-        bool ok = true;
+        const bool ok = true;
         std::vector<double> M[2];
         M[0].resize((size_t)KI * 32); M[1].resize((size_t)KI * 32);
         for (uint32_t s = 0; s < c->tapsets && ok; s++) {
@@ -856,15 +856,18 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                     memset(&T.h, 0, sizeof T.h);
                     T.h.am = (v == 2); T.h.post = (float)((double)c->in_scale / scale);
                     int ns = 0;
-                    for (int o = 0; o < (v == 2 ? 2 : 1); o++) {
-                        for (int src = 0; src < 2; src++)
+                    for (int o = 0; o < (v == 2 ? 2 : 1); o++)
+                        for (int src = 0; src < 2; src++) {
+                            int jlo = J, jhi = -1;                                   // chunks with any non-zero entry: one contiguous run
                             for (int j = 0; j < J; j++) {
                                 bool any = false;
                                 for (int m = 0; m < 16 && !any; m++)
                                     for (int b = 0; b < 32 && !any; b++) any = M[o][(size_t)(2 * (16 * j + m) + src) * 32 + b] != 0.0;
-                                if (!any) continue;
-                                if (ns >= kMfMaxSteps) { ok = false; break; }
-                                T.h.desc[ns++] = (src << 16) | j;
+                                if (any) { jlo = std::min(jlo, j); jhi = std::max(jhi, j); }
+                            }
+                            T.h.run[o][src].j0 = (jhi >= 0) ? jlo : 0;
+                            T.h.run[o][src].cnt = (jhi >= 0) ? jhi - jlo + 1 : 0;
+                            for (int j = jlo; j <= jhi; j++, ns++) {
                                 const size_t base = T.frags.size();
                                 T.frags.resize(base + 1024);                          // hi piece [64 lanes][8], then lo piece
                                 for (int l = 0; l < 64; l++)
@@ -875,8 +878,8 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                                         T.frags[base + 512 + l * 8 + jj] = (_Float16)(val - (double)vh);
                                     }
                             }
-                        if (o == 0) T.h.n0 = ns; else T.h.n1 = ns - T.h.n0;
-                    }
+                        }
+                    T.h.nsteps = ns;
                     bsteps = std::max(bsteps, ns);
                 }
         }

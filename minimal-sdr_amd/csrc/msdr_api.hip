@@ -635,6 +635,8 @@ struct msdr_chain {
     int mf_halo, mf_bsteps, mf_stride;
     char *d_mf_tab;
     BiquadCascadeTables<kMfL> *d_bq_mf;
+    BiquadCascadeTables<32> *d_bq_mf32;
+    int mf_waves;
     msdr_biquad_q15 *nodes[2];
     msdr_chain_info info;
     // optional per-launch timing of the main kernel
@@ -650,7 +652,7 @@ static void chain_free(msdr_chain *c)
     hipFree(c->d_taps); hipFree(c->d_osc); hipFree(c->d_mode); hipFree(c->d_tapset);
     hipFree(c->d_hist[0]); hipFree(c->d_hist[1]); hipFree(c->d_bq); hipFree(c->d_bq_state);
     hipFree(c->d_ftaps); hipFree(c->d_fset); hipFree(c->d_bq_fold);
-    hipFree(c->d_fft_h); hipFree(c->d_fft_tw); hipFree(c->d_bq_fft); hipFree(c->d_mf_tab); hipFree(c->d_bq_mf);
+    hipFree(c->d_fft_h); hipFree(c->d_fft_tw); hipFree(c->d_bq_fft); hipFree(c->d_mf_tab); hipFree(c->d_bq_mf); hipFree(c->d_bq_mf32);
     for (int k = 0; k < 2; k++) if (c->nodes[k]) msdr_biquad_q15_destroy(c->nodes[k]);
     for (auto &e : c->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete c;
@@ -883,7 +885,9 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                     bsteps = std::max(bsteps, ns);
                 }
         }
-        if (ok && bsteps > 0 && mf_lds_bytes(H, bsteps) <= 160 * 1024) {
+        // workgroup shape: 4 waves if three such workgroups fit a CU's LDS, else 8 waves (the B fragments are shared by more rows)
+        const int nw = (mf_lds_bytes(H, bsteps, 4) * 3 <= 160 * 1024) ? 4 : 8;
+        if (ok && bsteps > 0 && mf_lds_bytes(H, bsteps, nw) <= 160 * 1024) {
             const int stride = kMfHdrBytes + bsteps * 2048;
             std::vector<char> blob((size_t)stride * tabs.size(), 0);
             for (size_t t = 0; t < tabs.size(); t++) {
@@ -897,7 +901,12 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                 rc = upload(ctx, bt, &c->d_bq_mf);
             }
             if (!rc) {
-                c->mf_ok = true; c->mf_halo = H; c->mf_bsteps = bsteps; c->mf_stride = stride;
+                std::vector<BiquadCascadeTables<32>> bt(1);
+                make_cascade_tables<32>(cfg->biquad_coeffs, (int)c->nstages, &bt[0]);
+                rc = upload(ctx, bt, &c->d_bq_mf32);
+            }
+            if (!rc) {
+                c->mf_ok = true; c->mf_waves = nw; c->mf_halo = H; c->mf_bsteps = bsteps; c->mf_stride = stride;
             }
         }
     }
@@ -1018,8 +1027,8 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     const bool use_mf = f32 && c->mf_ok;
     if (use_mf) use_fft = false;
     if (use_fft || use_mf) use_fold = false;
-    const int kTile = use_mf ? kMfTile : use_fft ? kThreads * c->fft_LP : use_fold ? kFoldTile : kChainTile;
-    p.mf_tab = c->d_mf_tab; p.mf_stride = c->mf_stride; p.mf_halo = c->mf_halo; p.mf_bsteps = c->mf_bsteps; p.bq_mf = c->d_bq_mf;
+    const int kTile = use_mf ? c->mf_waves * kMfWaveTile : use_fft ? kThreads * c->fft_LP : use_fold ? kFoldTile : kChainTile;
+    p.mf_tab = c->d_mf_tab; p.mf_stride = c->mf_stride; p.mf_halo = c->mf_halo; p.mf_bsteps = c->mf_bsteps; p.bq_mf = c->d_bq_mf; p.bq_mf32 = c->d_bq_mf32; p.mf_waves = c->mf_waves;
     p.fft_h = c->d_fft_h; p.fft_tw = c->d_fft_tw; p.bq_fft = c->d_bq_fft;
     p.ftaps = c->d_ftaps; p.chan_fset = c->d_fset; p.fold_period = c->fold_P; p.bq_fold = c->d_bq_fold;
     p.fold_rot = c->fold_P ? (int)(c->phase % c->fold_P) : 0;
@@ -1049,7 +1058,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     nseg = (tiles + seg_tiles - 1) / seg_tiles;
     p.nseg = (int)nseg; p.seg_len = seg_tiles * kTile; p.warm = (int)(nseg > 1 ? warm_tiles * kTile : 0);
 
-    const size_t lds = use_mf ? mf_lds_bytes(c->mf_halo, c->mf_bsteps) : use_fft ? fft_lds_bytes() : use_fold ? fold_lds_bytes(p.ntaps_pad) : chain_lds_bytes(p.ntaps_pad);
+    const size_t lds = use_mf ? mf_lds_bytes(c->mf_halo, c->mf_bsteps, c->mf_waves) : use_fft ? fft_lds_bytes() : use_fold ? fold_lds_bytes(p.ntaps_pad) : chain_lds_bytes(p.ntaps_pad);
     const unsigned grid = (unsigned)(c->channels * nseg);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && c->events.size() < 8192) {
@@ -1057,7 +1066,9 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         HIP_TRY(hipEventRecord(e0, c->ctx->stream));
     }
     const char *kname = f32 ? "chain_kernel<ArithF32>" : "chain_kernel<ArithQ15>";
-    if (use_mf) { hipLaunchKernelGGL(chain_mfma_kernel, dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_mfma_kernel"; }
+    unsigned block = kThreads;
+    if (use_mf && c->mf_waves == 4) { hipLaunchKernelGGL(chain_mfma_kernel<4>, dim3(grid), dim3(256), lds, c->ctx->stream, p); kname = "chain_mfma_kernel<4>"; }
+    else if (use_mf) { block = 512; hipLaunchKernelGGL(chain_mfma_kernel<8>, dim3(grid), dim3(512), lds, c->ctx->stream, p); kname = "chain_mfma_kernel<8>"; }
     else if (use_fft && c->fft_LP == 15) { hipLaunchKernelGGL((chain_fft_kernel<15>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fft_kernel<15>"; }
     else if (use_fft) { hipLaunchKernelGGL((chain_fft_kernel<14>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fft_kernel<14>"; }
     else if (use_fold && c->fold_P == 4) { hipLaunchKernelGGL((chain_fold_kernel<4>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<4>"; }
@@ -1084,7 +1095,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     c->phase = (c->phase + (long long)(n_samples % c->osc_len)) % c->osc_len;
 
     snprintf(c->info.kernel, sizeof c->info.kernel, "%s", kname);
-    c->info.grid = grid; c->info.block = kThreads; c->info.lds_bytes = (uint32_t)lds;
+    c->info.grid = grid; c->info.block = block; c->info.lds_bytes = (uint32_t)lds;
     c->info.time_segments = (uint32_t)nseg; c->info.warmup = (uint32_t)p.warm; c->info.tile = (uint32_t)kTile;
     c->info.taps_padded = c->ntaps_pad;
     return 0;

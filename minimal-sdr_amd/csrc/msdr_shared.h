@@ -87,7 +87,9 @@ struct ChainParams {
     int mf_stride;
     int mf_halo;               // H: window samples before the tile, a multiple of 32 >= ntaps - 1
     int mf_bsteps;             // k-steps the LDS B region holds (max n0 + n1 over the tables)
-    const void *bq_mf;         // BiquadCascadeTables<16>
+    const void *bq_mf;         // BiquadCascadeTables<16>: 16-sample chunks
+    const void *bq_mf32;       // BiquadCascadeTables<32>: 32-sample blocks (msdr_biquad_paired.hiph)
+    int mf_waves;              // waves per workgroup: 4 or 8
 };
 
 }  // namespace msdr

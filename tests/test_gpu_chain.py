@@ -261,7 +261,7 @@ def test_chain_f32_folded_ssb_vs_oracle(ctx, orc, period, block, mode, engine):
     chain = msdr.Chain(ctx, msdr.ARITH_F32, 3, hi, hq, mixer=msdr.MIXER_NCO, mode=mode, osc_i=oi, osc_q=oq, biquad_coeffs=bq,
                        flags=ENGINES[engine])
     got = run_chain(ctx, chain, x, np.float32, block)
-    assert chain.info()["kernel"] == ("chain_mfma_kernel" if engine == "mfma" else "chain_fold_kernel<%d>" % period)
+    assert chain.info()["kernel"] == ("chain_mfma_kernel<4>" if engine == "mfma" else "chain_fold_kernel<%d>" % period)
     for c in range(3):
         want = orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq)
         assert rel_rms(got[c], want) < TOL, (c, rel_rms(got[c], want))
@@ -286,7 +286,7 @@ def test_chain_f32_folded_am_fs4_odd_blocks(ctx, orc, block, engine):
     bq = _f32_biquads(orc, 1)
     chain = msdr.Chain(ctx, msdr.ARITH_F32, 2, lp, lp, mixer=msdr.MIXER_FS4, mode=orclib.AM, biquad_coeffs=bq, flags=ENGINES[engine])
     got = run_chain(ctx, chain, x, np.float32, block)
-    assert chain.info()["kernel"] == ("chain_mfma_kernel" if engine == "mfma" else "chain_fold_kernel<4>")
+    assert chain.info()["kernel"] == ("chain_mfma_kernel<4>" if engine == "mfma" else "chain_fold_kernel<4>")
     cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
     for c in range(2):
         assert rel_rms(got[c], orc.chain_f32(x[c], orclib.AM, lp, lp, sin4, cos4, bq)) < TOL
@@ -303,7 +303,7 @@ def test_chain_f32_am_with_non_fs4_nco(ctx, orc, engine):
     chain = msdr.Chain(ctx, msdr.ARITH_F32, 2, hi, hq, mixer=msdr.MIXER_NCO, modes=np.array([orclib.AM, orclib.LSB], np.int32),
                        osc_i=oi, osc_q=oq, flags=ENGINES[engine])
     got = run_chain(ctx, chain, x, np.float32)
-    assert chain.info()["kernel"] == ("chain_mfma_kernel" if engine == "mfma" else "chain_kernel<ArithF32>")
+    assert chain.info()["kernel"] == ("chain_mfma_kernel<4>" if engine == "mfma" else "chain_kernel<ArithF32>")
     for c, m in enumerate((orclib.AM, orclib.LSB)):
         assert rel_rms(got[c], orc.chain_f32(x[c], m, hi, hq, oi, oq, None)) < TOL
 
@@ -364,7 +364,7 @@ def test_chain_f32_fft_time_segments_long_stream(ctx, orc, engine):
                        flags=ENGINES[engine])
     got = run_chain(ctx, chain, x, np.float32)
     info = chain.info()
-    assert info["kernel"] == ("chain_mfma_kernel" if engine == "mfma" else "chain_fft_kernel<15>") and info["time_segments"] > 1
+    assert info["kernel"] == ("chain_mfma_kernel<8>" if engine == "mfma" else "chain_fft_kernel<15>") and info["time_segments"] > 1
     want = orc.chain_f32(x[0], orclib.LSB, hi, hq, oi, oq, bq)
     assert rel_rms(got[0], want) < TOL
 
@@ -389,7 +389,7 @@ def test_chain_f32_mfma_tap_counts(ctx, orc, ntaps, mode):
         for block in (None, 4100):
             chain.reset()
             got = run_chain(ctx, chain, x, np.float32, block)
-            assert chain.info()["kernel"] == "chain_mfma_kernel", chain.info()
+            assert chain.info()["kernel"] == "chain_mfma_kernel<%d>" % (4 if ntaps <= 129 else 8), chain.info()
             for c in range(3):
                 want = orc.chain_f32(x[c], mode, hi, hq, sin4, cos4, bq)
                 assert rel_rms(got[c], want) < TOL, (n, block, c, rel_rms(got[c], want))
@@ -406,5 +406,5 @@ def test_chain_f32_mfma_weak_signal_keeps_fp32_accuracy(ctx, orc):
     for x in (weak, rail):
         chain = msdr.Chain(ctx, msdr.ARITH_F32, 1, hi, hq, mixer=msdr.MIXER_FS4, mode=orclib.USB)
         got = run_chain(ctx, chain, x, np.float32)
-        assert chain.info()["kernel"] == "chain_mfma_kernel"
+        assert chain.info()["kernel"] == "chain_mfma_kernel<4>"
         assert rel_rms(got[0], orc.chain_f32(x[0], orclib.USB, hi, hq, sin4, cos4, None)) < 2e-6

@@ -637,6 +637,12 @@ struct msdr_chain {
     BiquadCascadeTables<kMfL> *d_bq_mf;
     BiquadCascadeTables<32> *d_bq_mf32;
     int mf_waves;
+    std::vector<std::vector<float>> h_coef_i, h_coef_q;   // host copies for msdr_chain_set_mode
+    std::vector<double> h_osc, h_cnum;                    // oscillator pairs {cos, sin}; combined numerator
+    struct DHist { double v[8]; };
+    std::vector<DHist> dh_cache;                          // true numerator history per channel, valid while dh_gen == gen
+    std::vector<uint64_t> dh_gen;
+    uint64_t gen;                                         // process calls so far + 1
     msdr_biquad_q15 *nodes[2];
     msdr_chain_info info;
     // optional per-launch timing of the main kernel
@@ -696,8 +702,8 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         c->fft_LP = (cfg->num_taps <= 257) ? 15 : 14;
         c->hist_len = std::max<uint32_t>(c->hist_len, (uint32_t)(kFftF - kThreads * c->fft_LP));   // the FFT block's history
     }
-    if (f32 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && mf_halo((int)cfg->num_taps) <= 2048)      // the matrix-core kernel's window halo
-        c->hist_len = std::max<uint32_t>(c->hist_len, (uint32_t)mf_halo((int)cfg->num_taps));
+    if (f32 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && mf_halo((int)(cfg->num_taps + 2 * cfg->num_biquad_stages)) <= 2048)      // the matrix-core kernel's window halo
+        c->hist_len = std::max<uint32_t>(c->hist_len, (uint32_t)mf_halo((int)(cfg->num_taps + 2 * cfg->num_biquad_stages)));
     c->osc_len = (cfg->mixer == MSDR_MIXER_NCO) ? cfg->osc_len : 4;
     c->in_scale = (cfg->in_scale == 0.0f) ? 1.0f / 32768.0f : cfg->in_scale;
     c->nstages = f32 ? cfg->num_biquad_stages : 0;
@@ -705,6 +711,26 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->time_segments = cfg->time_segments; c->warmup_cfg = cfg->biquad_warmup;
     c->pole_radius = c->nstages ? max_pole_radius(cfg->biquad_coeffs, (int)c->nstages) : 0.0;
     c->cur = 0; c->phase = 0; c->timing = false; c->timed_ms = 0; c->timed_launches = 0;
+    c->gen = 1; c->dh_cache.resize(c->channels); c->dh_gen.assign(c->channels, 0);
+    if (f32) {
+        c->h_coef_i.resize(c->tapsets); c->h_coef_q.resize(c->tapsets);
+        for (uint32_t s = 0; s < c->tapsets; s++) {
+            c->h_coef_i[s].assign((const float *)cfg->coeffs_i[s], (const float *)cfg->coeffs_i[s] + c->ntaps);
+            c->h_coef_q[s].assign((const float *)cfg->coeffs_q[s], (const float *)cfg->coeffs_q[s] + c->ntaps);
+        }
+        c->h_osc.resize((size_t)c->osc_len * 2);
+        for (uint32_t k = 0; k < c->osc_len; k++) {
+            if (cfg->mixer == MSDR_MIXER_NCO) { c->h_osc[2 * k] = ((const float *)cfg->osc_q)[k]; c->h_osc[2 * k + 1] = ((const float *)cfg->osc_i)[k]; }
+            else { const double c4[4] = {1, 0, -1, 0}, s4[4] = {0, 1, 0, -1}; c->h_osc[2 * k] = c4[k]; c->h_osc[2 * k + 1] = s4[k]; }
+        }
+        c->h_cnum.assign(1, 1.0);
+        for (uint32_t st = 0; st < c->nstages; st++) {
+            std::vector<double> nx(c->h_cnum.size() + 2, 0.0);
+            for (size_t i = 0; i < c->h_cnum.size(); i++)
+                for (int k = 0; k < 3; k++) nx[i + k] += c->h_cnum[i] * (double)cfg->biquad_coeffs[5 * st + k];
+            c->h_cnum.swap(nx);
+        }
+    }
     memset(&c->info, 0, sizeof c->info);
 
     int rc = 0;
@@ -821,8 +847,16 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     }
     // ---- matrix-core tables (F32, short-period oscillator): B fragments per (tap set x {LSB, USB, envelope}, rotation) ----
     c->mf_ok = false;
-    if (!rc && f32 && c->fold_P > 0 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && mf_halo((int)c->ntaps) <= 2048) {
-        const int P = c->fold_P, N = (int)c->ntaps, H = mf_halo(N), J = H / 32 + 1, KI = H + 32;
+    if (!rc && f32 && c->fold_P > 0 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && mf_halo((int)(c->ntaps + 2 * c->nstages)) <= 2048) {
+        // SSB tables carry the cascade's numerator C(z) = prod (b0 + b1 z^-1 + b2 z^-2): the FIR grows by 2 taps per section
+        const int P = c->fold_P, N = (int)c->ntaps, NF = N + 2 * (int)c->nstages, H = mf_halo(NF), J = H / 32 + 1, KI = H + 32;
+        std::vector<double> cnum(1, 1.0);
+        for (uint32_t st = 0; st < c->nstages; st++) {
+            std::vector<double> nx(cnum.size() + 2, 0.0);
+            for (size_t i = 0; i < cnum.size(); i++)
+                for (int k = 0; k < 3; k++) nx[i + k] += cnum[i] * (double)cfg->biquad_coeffs[5 * st + k];
+            cnum.swap(nx);
+        }
         std::vector<double> oc(P), os(P);
         if (cfg->mixer == MSDR_MIXER_FS4) { const double c4[4] = {1, 0, -1, 0}, s4[4] = {0, 1, 0, -1}; for (int k = 0; k < 4; k++) { oc[k] = c4[k]; os[k] = s4[k]; } }
         else for (int k = 0; k < P; k++) { oc[k] = ((const float *)cfg->osc_q)[k]; os[k] = ((const float *)cfg->osc_i)[k]; }
@@ -832,21 +866,31 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         const bool ok = true;
         std::vector<double> M[2];
         M[0].resize((size_t)KI * 32); M[1].resize((size_t)KI * 32);
+        std::vector<double> di(NF), dq(NF), fi(NF), fq(NF);
         for (uint32_t s = 0; s < c->tapsets && ok; s++) {
             const float *hi = (const float *)cfg->coeffs_i[s], *hq = (const float *)cfg->coeffs_q[s];
+            // taps by delay (arm_fir keeps its coefficients time-reversed: index N - 1 - delay); plain and numerator-folded
+            std::fill(di.begin(), di.end(), 0.0); std::fill(dq.begin(), dq.end(), 0.0);
+            std::fill(fi.begin(), fi.end(), 0.0); std::fill(fq.begin(), fq.end(), 0.0);
+            for (int dl = 0; dl < N; dl++) {
+                di[dl] = hi[N - 1 - dl]; dq[dl] = hq[N - 1 - dl];
+                for (size_t i = 0; i < cnum.size(); i++) { fi[dl + i] += cnum[i] * di[dl]; fq[dl + i] += cnum[i] * dq[dl]; }
+            }
             for (int v = 0; v < 3 && ok; v++)
                 for (int rot = 0; rot < P && ok; rot++) {
-                    // B[i][b]: window sample i (oscillator phase (rot + i) mod P) meets output column b at delay H + b - i,
-                    // i.e. coefficient index N - 1 - delay (arm_fir keeps its coefficients time-reversed)
+                    // B[i][b]: window sample i (oscillator phase (rot + i) mod P) meets output column b at delay H + b - i
+                    const bool numfold = (v != 2) && c->nstages > 0;
+                    const std::vector<double> &ti = numfold ? fi : di, &tq = numfold ? fq : dq;
+                    const int nt = numfold ? NF : N;
                     double maxabs = 0.0;
                     for (int i = 0; i < KI; i++)
                         for (int b = 0; b < 32; b++) {
                             const int delay = H + b - i;
                             double m0 = 0.0, m1 = 0.0;
-                            if (delay >= 0 && delay < N) {
-                                const int k = N - 1 - delay, psi = (rot + i) % P;
-                                if (v == 2) { m0 = (double)hi[k] * oc[psi]; m1 = (double)hq[k] * os[psi]; }
-                                else m0 = (double)hi[k] * oc[psi] + (v == 0 ? -1.0 : 1.0) * (double)hq[k] * os[psi];
+                            if (delay >= 0 && delay < nt) {
+                                const int psi = (rot + i) % P;
+                                if (v == 2) { m0 = di[delay] * oc[psi]; m1 = dq[delay] * os[psi]; }
+                                else m0 = ti[delay] * oc[psi] + (v == 0 ? -1.0 : 1.0) * tq[delay] * os[psi];
                             }
                             M[0][(size_t)i * 32 + b] = m0; M[1][(size_t)i * 32 + b] = m1;
                             maxabs = std::max(maxabs, std::max(std::fabs(m0), std::fabs(m1)));
@@ -856,7 +900,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                     const double scale = std::ldexp(1.0, ex);
                     Tab &T = tabs[((size_t)s * 3 + v) * P + rot];
                     memset(&T.h, 0, sizeof T.h);
-                    T.h.am = (v == 2); T.h.post = (float)((double)c->in_scale / scale);
+                    T.h.am = (v == 2); T.h.numfold = numfold; T.h.post = (float)((double)c->in_scale / scale);
                     int ns = 0;
                     for (int o = 0; o < (v == 2 ? 2 : 1); o++)
                         for (int src = 0; src < 2; src++) {
@@ -1091,7 +1135,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
                        d_if, (const int16_t *)c->d_hist[c->cur], c->d_hist[c->cur ^ 1], (long long)n_samples, (int)c->hist_len,
                        (int)c->channels);
     if (int rc = launch_check("history_kernel")) return rc;
-    c->cur ^= 1;
+    c->cur ^= 1; c->gen++;
     c->phase = (c->phase + (long long)(n_samples % c->osc_len)) % c->osc_len;
 
     snprintf(c->info.kernel, sizeof c->info.kernel, "%s", kname);
@@ -1110,7 +1154,7 @@ extern "C" int msdr_chain_reset(msdr_chain *c)
     HIP_TRY(hipMemsetAsync(c->d_hist[1], 0, hb, c->ctx->stream));
     if (c->d_bq_state) HIP_TRY(hipMemsetAsync(c->d_bq_state, 0, (size_t)c->channels * kBqStateFloats * sizeof(float), c->ctx->stream));
     // the reference never clears biquad history on retune (filter_biquad.cpp:95-97); init_FIR() only zeroes the FIR state.
-    c->phase = 0;
+    c->phase = 0; c->gen++;
     return 0;
 }
 
@@ -1120,6 +1164,55 @@ extern "C" int msdr_chain_set_mode(msdr_chain *c, uint32_t channel, int32_t mode
     if (int rc = bind(c->ctx)) return rc;
     if (channel >= c->channels || mode < MSDR_MODE_SYNCAM || mode > MSDR_MODE_CW || tapset < 0 || (uint32_t)tapset >= c->tapsets)
         return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad channel/mode/tapset");
+    // The matrix-core kernel's SSB tables fold the cascade's numerator C(z) into the FIR (msdr_chain_mfma.hiph): such a mode
+    // neither maintains nor reads the numerator history d[n-1-k] of the carried state.  Keep the stream exact across a
+    // retune: D = the history as the cascade has really seen it (from the state, or rebuilt from the raw IF history with the
+    // old mode's taps); an unfolded new mode gets D; a folded one gets the correction sum_k c[j+1+k] (D[k] - D'[k]) to its
+    // first samples j, D' = the history its own FIR implies.
+    {
+        const int old_mode = c->h_mode[channel], old_ts = c->h_tapset[channel];
+        auto folded = [&](int m) { return c->arith == MSDR_ARITH_F32 && c->mf_ok && c->nstages > 0 && (m == MSDR_MODE_LSB || m == MSDR_MODE_USB); };
+        if ((folded(old_mode) || folded(mode)) && (old_mode != mode || old_ts != tapset)) {
+            HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+            std::vector<int16_t> hist(c->hist_len);
+            float st[kBqStateFloats];
+            HIP_TRY(hipMemcpy(hist.data(), c->d_hist[c->cur] + (size_t)channel * c->hist_len, hist.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(st, c->d_bq_state + (size_t)channel * kBqStateFloats, sizeof st, hipMemcpyDeviceToHost));
+            const int N = (int)c->ntaps, HL = (int)c->hist_len, OL = (int)c->osc_len;
+            auto ssb_history = [&](int m, int ts, double *D) {           // d[-1-k], k < 8, of an SSB mode from the raw history
+                const float *hi = c->h_coef_i[ts].data(), *hq = c->h_coef_q[ts].data();
+                const double sign = (m == MSDR_MODE_LSB) ? -1.0 : 1.0;
+                for (int k = 0; k < 8; k++) {
+                    double acc = 0.0;
+                    for (int dl = 0; dl < N; dl++) {
+                        const int t = -1 - k - dl, hx = HL + t;
+                        if (hx < 0) break;
+                        const int ph = (int)((((long long)c->phase + t) % OL + OL) % OL);
+                        const double x = (double)hist[hx] * (double)c->in_scale;
+                        acc += (double)hi[N - 1 - dl] * (x * c->h_osc[2 * ph]) + sign * (double)hq[N - 1 - dl] * (x * c->h_osc[2 * ph + 1]);
+                    }
+                    D[k] = acc;
+                }
+            };
+            double D[8];
+            if (c->dh_gen[channel] == c->gen) memcpy(D, c->dh_cache[channel].v, sizeof D);      // retuned again before any sample was processed
+            else if (folded(old_mode)) ssb_history(old_mode, old_ts, D);
+            else for (int k = 0; k < 8; k++) D[k] = st[k];
+            memcpy(c->dh_cache[channel].v, D, sizeof D); c->dh_gen[channel] = c->gen;
+            float out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (folded(mode)) {
+                double Dn[8];
+                ssb_history(mode, tapset, Dn);
+                const int H2 = 2 * (int)c->nstages;
+                for (int j = 0; j < H2; j++) {
+                    double a = 0.0;
+                    for (int k = 0; j + 1 + k <= H2; k++) a += c->h_cnum[j + 1 + k] * (D[k] - Dn[k]);
+                    out[j] = (float)a;
+                }
+            } else for (int k = 0; k < 8; k++) out[k] = (float)D[k];
+            HIP_TRY(hipMemcpy(c->d_bq_state + (size_t)channel * kBqStateFloats, out, sizeof out, hipMemcpyHostToDevice));
+        }
+    }
     c->h_mode[channel] = mode; c->h_tapset[channel] = tapset;
     if (c->d_fset) {
         const int fs = tapset * 3 + (mode == MSDR_MODE_LSB ? 0 : mode == MSDR_MODE_USB ? 1 : 2);

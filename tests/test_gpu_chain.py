@@ -408,3 +408,30 @@ def test_chain_f32_mfma_weak_signal_keeps_fp32_accuracy(ctx, orc):
         got = run_chain(ctx, chain, x, np.float32)
         assert chain.info()["kernel"] == "chain_mfma_kernel<4>"
         assert rel_rms(got[0], orc.chain_f32(x[0], orclib.USB, hi, hq, sin4, cos4, None)) < 2e-6
+
+
+@pytest.mark.parametrize("engine", ["mfma", "valu"])
+def test_chain_f32_retune_mid_stream_keeps_cascade_state(ctx, orc, engine):
+    """msdr_chain_set_mode between calls: FIR history and biquad state carry over, as in the oracle with a carried state.
+    The matrix-core kernel's SSB modes fold the cascade's numerator into the FIR; entering / leaving / changing such a mode
+    must not show (numerator history rebuilt, resp. a correction to the first samples)."""
+    rng = np.random.default_rng(55)
+    hi, hq = _hilbert_pair(100)
+    bq = _f32_biquads(orc, 2)
+    cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+    x = rng.integers(-8000, 8001, (2, 6 * 1500)).astype(np.int16)
+    plan = [orclib.LSB, orclib.AM, orclib.USB, orclib.LSB, orclib.CW, orclib.USB]     # channel 0; channel 1 stays LSB
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 2, hi, hq, mixer=msdr.MIXER_FS4, mode=orclib.LSB, biquad_coeffs=bq, flags=ENGINES[engine])
+    st0, st1 = {}, {}
+    for k, m in enumerate(plan):
+        if k:
+            chain.set_mode(0, m, 0)
+            if k == 3:                       # retuned twice before the next sample
+                chain.set_mode(0, orclib.AM, 0)
+                chain.set_mode(0, m, 0)
+        seg = x[:, 1500 * k:1500 * (k + 1)]
+        got = run_chain(ctx, chain, seg, np.float32)
+        want0 = orc.chain_f32(seg[0], m, hi, hq, sin4, cos4, bq, state=st0)
+        want1 = orc.chain_f32(seg[1], orclib.LSB, hi, hq, sin4, cos4, bq, state=st1)
+        assert rel_rms(got[0], want0) < TOL, (k, m, rel_rms(got[0], want0))
+        assert rel_rms(got[1], want1) < TOL, (k, rel_rms(got[1], want1))

@@ -27,6 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "minimal-sdr_amd", "python"))
 FS = 24000.0
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 matrix peak (same guide)
 
 
 def hilbert_pair(n_taps, fc=1330.0, bw=1920.0):
@@ -375,6 +376,16 @@ def main():
                      "valu_peak_tflops": VALU_PEAK_TFLOPS,
                      "as_written_equivalent_tflops": round(flop_written * samples_per_step / (k_ms * 1e-3) / 1e12, 2)},
     }
+    if info["kernel"].startswith("chain_mfma"):
+        # matrix-core kernel: the folded FIR runs as 3 v_mfma_f32_32x32x16_f16 (32768 flop each) per k-step and 1024-output
+        # wave tile; the vector ALU only carries staging, demod and the IIR scan, so the valu_* fields do not apply
+        r = out["roofline"]
+        for k in ("valu_tflops_executed", "valu_frac_executed", "valu_peak_tflops"):
+            r.pop(k)
+        mf = 3 * 32768.0 * info["mfma_ksteps"] / 1024.0
+        r["mfma_f16_tflops_executed"] = round(mf * samples_per_step / (k_ms * 1e-3) / 1e12, 1)
+        r["mfma_f16_frac"] = round(mf * samples_per_step / (k_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
+        r["mfma_f16_peak_tflops"] = MFMA_F16_PEAK_TFLOPS
     if gather:
         out["gather"] = gather
     if not args.no_cpu and world == 1:

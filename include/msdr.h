@@ -209,6 +209,7 @@ typedef struct {
 #define MSDR_CHAIN_NO_TAP_FOLDING 1u /* F32: keep mixer and FIR pair as separate arithmetic steps (as written) */
 #define MSDR_CHAIN_NO_FFT 4u         /* F32: never use the overlap-save FFT kernel (long FIRs stay sliding dot products) */
 #define MSDR_CHAIN_NO_MFMA 8u        /* F32: never run the folded FIR on the matrix cores (split-fp16 MFMA kernel) */
+#define MSDR_CHAIN_MFMA_WG 16u       /* F32: matrix-core kernel with workgroup tiles (msdr_chain_mfma.hiph) instead of one wave per stream */
 
 typedef struct msdr_chain msdr_chain;
 int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_chain **out);
@@ -226,6 +227,7 @@ typedef struct {
     uint32_t grid, block, lds_bytes;
     uint32_t time_segments, warmup, tile;
     uint32_t taps_padded;
+    uint32_t mfma_ksteps;            /* matrix-core kernel: 16-sample k-steps (3 MFMAs each) per 1024-output wave tile, else 0 */
 } msdr_chain_info;
 int msdr_chain_get_info(msdr_chain *chain, msdr_chain_info *info);
 /* Measurement aid (bench.py): when enabled every msdr_chain_process() brackets its MAIN kernel with

@@ -6,7 +6,9 @@
 #include "msdr_kernels.hiph"
 #include "msdr_chain_fold.hiph"
 #include "msdr_chain_fft.hiph"
+#include <type_traits>
 #include "msdr_chain_mfma.hiph"
+#include "msdr_chain_mfw.hiph"
 #include "msdr_design.h"
 
 #include <algorithm>
@@ -14,6 +16,7 @@
 #include <complex>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -53,6 +56,7 @@ struct msdr_ctx {
     int device;
     hipStream_t stream;
     bool owns_stream;
+    int num_cus;
     void *scratch;          // small device buffer reused for per-call host tables (oscillator tables)
     size_t scratch_bytes;
 };
@@ -91,7 +95,7 @@ extern "C" int msdr_ctx_create(int device, void *hip_stream, msdr_ctx **out)
     HIP_TRY(hipSetDevice(device));
     msdr_ctx *c = new (std::nothrow) msdr_ctx();
     if (!c) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
-    c->device = device;
+    c->device = device; c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->scratch = nullptr; c->scratch_bytes = 0;
     c->owns_stream = (hip_stream == nullptr);
     c->stream = (hipStream_t)hip_stream;
@@ -637,6 +641,15 @@ struct msdr_chain {
     BiquadCascadeTables<kMfL> *d_bq_mf;
     BiquadCascadeTables<32> *d_bq_mf32;
     int mf_waves;
+    // wave-stream variant (msdr_chain_mfw.hiph): waves per workgroup, resident waves per CU, unit table and its cache key
+    uint32_t flags;
+    int mfw_nw, mfw_waves_per_cu;
+    float *d_bq_state_alt;
+    int *d_units;
+    size_t units_cap;
+    uint64_t mode_gen, units_mode_gen;
+    long long units_nseg;
+    uint32_t units_wgs;
     std::vector<std::vector<float>> h_coef_i, h_coef_q;   // host copies for msdr_chain_set_mode
     std::vector<double> h_osc, h_cnum;                    // oscillator pairs {cos, sin}; combined numerator
     struct DHist { double v[8]; };
@@ -659,6 +672,7 @@ static void chain_free(msdr_chain *c)
     hipFree(c->d_hist[0]); hipFree(c->d_hist[1]); hipFree(c->d_bq); hipFree(c->d_bq_state);
     hipFree(c->d_ftaps); hipFree(c->d_fset); hipFree(c->d_bq_fold);
     hipFree(c->d_fft_h); hipFree(c->d_fft_tw); hipFree(c->d_bq_fft); hipFree(c->d_mf_tab); hipFree(c->d_bq_mf); hipFree(c->d_bq_mf32);
+    hipFree(c->d_bq_state_alt); hipFree(c->d_units);
     for (int k = 0; k < 2; k++) if (c->nodes[k]) msdr_biquad_q15_destroy(c->nodes[k]);
     for (auto &e : c->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete c;
@@ -712,6 +726,8 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->pole_radius = c->nstages ? max_pole_radius(cfg->biquad_coeffs, (int)c->nstages) : 0.0;
     c->cur = 0; c->phase = 0; c->timing = false; c->timed_ms = 0; c->timed_launches = 0;
     c->gen = 1; c->dh_cache.resize(c->channels); c->dh_gen.assign(c->channels, 0);
+    c->flags = cfg->flags; c->mfw_nw = 0; c->mfw_waves_per_cu = 0; c->d_bq_state_alt = nullptr; c->d_units = nullptr; c->units_cap = 0;
+    c->mode_gen = 1; c->units_mode_gen = 0; c->units_nseg = 0; c->units_wgs = 0;
     if (f32) {
         c->h_coef_i.resize(c->tapsets); c->h_coef_q.resize(c->tapsets);
         for (uint32_t s = 0; s < c->tapsets; s++) {
@@ -951,6 +967,17 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
             }
             if (!rc) {
                 c->mf_ok = true; c->mf_waves = nw; c->mf_halo = H; c->mf_bsteps = bsteps; c->mf_stride = stride;
+                // wave-stream variant: waves per workgroup that put the most waves on a CU (<= 16: the kernel's <= 128 VGPRs allow
+                // 4 per SIMD) under the 160 KB of LDS; ties go to the smaller workgroup
+                int best = 0;
+                for (int w = 1; w <= 16; w++) {
+                    const size_t l = mw_lds_bytes(H, bsteps, w);
+                    if (l > 160 * 1024) break;
+                    const int wgs = std::min<int>((int)((160 * 1024) / l), 16 / w);
+                    if (wgs * w > best) { best = wgs * w; c->mfw_nw = w; }
+                }
+                c->mfw_waves_per_cu = best;
+                if (best > 0) rc = dzalloc(ctx, (size_t)c->channels * kBqStateFloats, &c->d_bq_state_alt);
             }
         }
     }
@@ -1069,9 +1096,10 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             if (m != MSDR_MODE_LSB && m != MSDR_MODE_USB && !c->fft_am_ok[c->h_tapset[ch]]) { use_fft = false; break; }
         }
     const bool use_mf = f32 && c->mf_ok;
+    const bool use_mfw = use_mf && c->mfw_nw > 0 && !(c->flags & MSDR_CHAIN_MFMA_WG);
     if (use_mf) use_fft = false;
     if (use_fft || use_mf) use_fold = false;
-    const int kTile = use_mf ? c->mf_waves * kMfWaveTile : use_fft ? kThreads * c->fft_LP : use_fold ? kFoldTile : kChainTile;
+    const int kTile = use_mfw ? kMwTile : use_mf ? c->mf_waves * kMfWaveTile : use_fft ? kThreads * c->fft_LP : use_fold ? kFoldTile : kChainTile;
     p.mf_tab = c->d_mf_tab; p.mf_stride = c->mf_stride; p.mf_halo = c->mf_halo; p.mf_bsteps = c->mf_bsteps; p.bq_mf = c->d_bq_mf; p.bq_mf32 = c->d_bq_mf32; p.mf_waves = c->mf_waves;
     p.fft_h = c->d_fft_h; p.fft_tw = c->d_fft_tw; p.bq_fft = c->d_bq_fft;
     p.ftaps = c->d_ftaps; p.chan_fset = c->d_fset; p.fold_period = c->fold_P; p.bq_fold = c->d_bq_fold;
@@ -1085,14 +1113,27 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         long long w = c->warmup_cfg;
         if (w == 0) {
             if (c->pole_radius >= 0.99999) can_split = false;        // marginal/unstable: never re-converges
-            else if (c->pole_radius > 0) w = (long long)std::ceil(std::log(1e-10) / std::log(c->pole_radius)) + 64 * c->nstages;
+            else if (c->pole_radius > 0) w = (long long)std::ceil(std::log(use_mfw ? 1e-8 : 1e-10) / std::log(c->pole_radius)) + 64 * c->nstages;
         }
         warm_tiles = (w + kTile - 1) / kTile;
-        if (warm_tiles > 64) can_split = false;
+        if (warm_tiles > 64 * (use_mfw ? 4 : 1)) can_split = false;
     }
     long long nseg = 1;
     if (c->time_segments == 1 || !can_split) nseg = 1;
-    else {
+    else if (use_mfw && c->time_segments == 0) {
+        // one unit per wave, all units equally long: the launch takes ceil(units / resident waves) rounds of (segment + warm-up)
+        // tiles.  Pick the segment count that minimises that product (an exact multiple of the resident waves wins).
+        const long long slots = (long long)c->mfw_waves_per_cu * c->ctx->num_cus;
+        const long long max_nseg = std::max<long long>(1, tiles / std::max<long long>(4, 8 * warm_tiles));
+        const long long kmax = std::min<long long>(max_nseg, std::max<long long>(1, (8 * slots + c->channels - 1) / c->channels));
+        double best = 1e300;
+        for (long long k = 1; k <= kmax; k++) {
+            const long long st = (tiles + k - 1) / k, ns = (tiles + st - 1) / st;
+            const long long rounds = ((long long)c->channels * ns + slots - 1) / slots;
+            const double cost = (double)rounds * (double)(st + (ns > 1 ? warm_tiles : 0));
+            if (cost < best * 0.999) { best = cost; nseg = ns; }
+        }
+    } else {
         long long min_seg_tiles = std::max<long long>(4, 32 * warm_tiles);   // <= ~3 % redone work
         long long max_nseg = std::max<long long>(1, tiles / min_seg_tiles);
         long long want = c->time_segments > 1 ? c->time_segments : std::max<long long>(1, (2048 + c->channels - 1) / c->channels);
@@ -1102,8 +1143,47 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     nseg = (tiles + seg_tiles - 1) / seg_tiles;
     p.nseg = (int)nseg; p.seg_len = seg_tiles * kTile; p.warm = (int)(nseg > 1 ? warm_tiles * kTile : 0);
 
-    const size_t lds = use_mf ? mf_lds_bytes(c->mf_halo, c->mf_bsteps, c->mf_waves) : use_fft ? fft_lds_bytes() : use_fold ? fold_lds_bytes(p.ntaps_pad) : chain_lds_bytes(p.ntaps_pad);
-    const unsigned grid = (unsigned)(c->channels * nseg);
+    unsigned grid = (unsigned)(c->channels * nseg);
+    if (use_mfw) {
+        // unit table: (channel, segment) per wave; the waves of a workgroup share one tap table, so channels are grouped by
+        // table set and every group is padded to whole workgroups
+        const int nw = c->mfw_nw;
+        if (c->units_mode_gen != c->mode_gen || c->units_nseg != nseg) {
+            std::vector<uint32_t> order(c->channels);
+            for (uint32_t i = 0; i < c->channels; i++) order[i] = i;
+            auto fset_of = [&](uint32_t ch) { const int m = c->h_mode[ch]; return c->h_tapset[ch] * 3 + (m == MSDR_MODE_LSB ? 0 : m == MSDR_MODE_USB ? 1 : 2); };
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return fset_of(a) < fset_of(b); });
+            std::vector<int> units;
+            units.reserve(((size_t)c->channels * nseg + 3 * MSDR_MAX_TAPSETS * nw) * 2);
+            for (size_t i = 0; i < order.size(); i++) {
+                if (i > 0 && fset_of(order[i]) != fset_of(order[i - 1]))
+                    while ((units.size() / 2) % nw) { units.push_back(-1); units.push_back(0); }
+                for (long long sg = 0; sg < nseg; sg++) { units.push_back((int)order[i]); units.push_back((int)sg); }
+            }
+            while ((units.size() / 2) % nw) { units.push_back(-1); units.push_back(0); }
+            if (units.size() > c->units_cap) {
+                HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+                hipFree(c->d_units); c->d_units = nullptr; c->units_cap = 0;
+                if (int rc = dzalloc(c->ctx, units.size(), &c->d_units)) return rc;
+                c->units_cap = units.size();
+            }
+            HIP_TRY(hipMemcpyAsync(c->d_units, units.data(), units.size() * sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));
+            HIP_TRY(hipStreamSynchronize(c->ctx->stream));        // `units` is a local
+            c->units_mode_gen = c->mode_gen; c->units_nseg = nseg; c->units_wgs = (uint32_t)(units.size() / 2 / nw);
+        }
+        grid = c->units_wgs;
+        p.mf_units = c->d_units; p.mf_nw = nw; p.bq_state_out = c->d_bq_state_alt;
+        { const char *e = getenv("MSDR_DBG"); p.dbg = e ? atoi(e) : 0; }
+#ifdef MSDR_STAMPS
+        static unsigned long long *stamp_buf = nullptr;
+        const size_t stamp_n = (size_t)grid * nw * 8;
+        if (!stamp_buf) HIP_TRY(hipMalloc(&stamp_buf, (1u << 20) * 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(stamp_buf, 0, stamp_n * 8, c->ctx->stream));
+        p.dbg_buf = stamp_buf;
+#endif
+    }
+
+    const size_t lds = use_mfw ? mw_lds_bytes(c->mf_halo, c->mf_bsteps, c->mfw_nw) : use_mf ? mf_lds_bytes(c->mf_halo, c->mf_bsteps, c->mf_waves) : use_fft ? fft_lds_bytes() : use_fold ? fold_lds_bytes(p.ntaps_pad) : chain_lds_bytes(p.ntaps_pad);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && c->events.size() < 8192) {
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -1111,7 +1191,32 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     }
     const char *kname = f32 ? "chain_kernel<ArithF32>" : "chain_kernel<ArithQ15>";
     unsigned block = kThreads;
-    if (use_mf && c->mf_waves == 4) { hipLaunchKernelGGL(chain_mfma_kernel<4>, dim3(grid), dim3(256), lds, c->ctx->stream, p); kname = "chain_mfma_kernel<4>"; }
+    if (use_mfw) {
+        block = (unsigned)c->mfw_nw * 64;
+        switch (c->nstages) {
+        case 0: hipLaunchKernelGGL(chain_mfw_kernel<0>, dim3(grid), dim3(block), lds, c->ctx->stream, p); break;
+        case 1: hipLaunchKernelGGL(chain_mfw_kernel<1>, dim3(grid), dim3(block), lds, c->ctx->stream, p); break;
+        case 2: hipLaunchKernelGGL(chain_mfw_kernel<2>, dim3(grid), dim3(block), lds, c->ctx->stream, p); break;
+        case 3: hipLaunchKernelGGL(chain_mfw_kernel<3>, dim3(grid), dim3(block), lds, c->ctx->stream, p); break;
+        default: hipLaunchKernelGGL(chain_mfw_kernel<4>, dim3(grid), dim3(block), lds, c->ctx->stream, p); break;
+        }
+        static const char *const names[5] = {"chain_mfw_kernel<0>", "chain_mfw_kernel<1>", "chain_mfw_kernel<2>", "chain_mfw_kernel<3>", "chain_mfw_kernel<4>"};
+        kname = names[c->nstages];
+        std::swap(c->d_bq_state, c->d_bq_state_alt);          // the kernel read bq_state and wrote bq_state_out
+#ifdef MSDR_STAMPS
+        if (getenv("MSDR_STAMP_PRINT")) {
+            HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+            std::vector<unsigned long long> h((size_t)grid * c->mfw_nw * 8);
+            HIP_TRY(hipMemcpy(h.data(), p.dbg_buf, h.size() * 8, hipMemcpyDeviceToHost));
+            double sum[8] = {0}; size_t cnt = 0;
+            for (size_t u = 0; u < h.size() / 8; u++) { if (!h[u * 8 + 0] && !h[u * 8 + 1]) continue; cnt++; for (int k = 0; k < 8; k++) sum[k] += (double)h[u * 8 + k]; }
+            const double tl = (double)((n_samples + kMwTile - 1) / kMwTile) * c->channels / std::max<size_t>(cnt, 1);
+            fprintf(stderr, "stamps (cycles per tile per wave, %zu units, %.1f tiles each): prefetch-issue %.0f | mfma %.0f | demod+swap %.0f | iir %.0f | store %.0f | halo %.0f | vmwait %.0f | stage %.0f\n",
+                    cnt, tl, sum[0] / cnt / tl, sum[1] / cnt / tl, sum[2] / cnt / tl, sum[3] / cnt / tl, sum[4] / cnt / tl, sum[5] / cnt / tl, sum[6] / cnt / tl, sum[7] / cnt / tl);
+        }
+#endif
+    }
+    else if (use_mf && c->mf_waves == 4) { hipLaunchKernelGGL(chain_mfma_kernel<4>, dim3(grid), dim3(256), lds, c->ctx->stream, p); kname = "chain_mfma_kernel<4>"; }
     else if (use_mf) { block = 512; hipLaunchKernelGGL(chain_mfma_kernel<8>, dim3(grid), dim3(512), lds, c->ctx->stream, p); kname = "chain_mfma_kernel<8>"; }
     else if (use_fft && c->fft_LP == 15) { hipLaunchKernelGGL((chain_fft_kernel<15>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fft_kernel<15>"; }
     else if (use_fft) { hipLaunchKernelGGL((chain_fft_kernel<14>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fft_kernel<14>"; }
@@ -1142,6 +1247,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     c->info.grid = grid; c->info.block = block; c->info.lds_bytes = (uint32_t)lds;
     c->info.time_segments = (uint32_t)nseg; c->info.warmup = (uint32_t)p.warm; c->info.tile = (uint32_t)kTile;
     c->info.taps_padded = c->ntaps_pad;
+    c->info.mfma_ksteps = use_mf ? (uint32_t)c->mf_bsteps : 0u;
     return 0;
 }
 
@@ -1152,6 +1258,7 @@ extern "C" int msdr_chain_reset(msdr_chain *c)
     size_t hb = (size_t)c->channels * c->hist_len * sizeof(int16_t);
     HIP_TRY(hipMemsetAsync(c->d_hist[0], 0, hb, c->ctx->stream));
     HIP_TRY(hipMemsetAsync(c->d_hist[1], 0, hb, c->ctx->stream));
+    if (c->d_bq_state_alt) HIP_TRY(hipMemsetAsync(c->d_bq_state_alt, 0, (size_t)c->channels * kBqStateFloats * sizeof(float), c->ctx->stream));
     if (c->d_bq_state) HIP_TRY(hipMemsetAsync(c->d_bq_state, 0, (size_t)c->channels * kBqStateFloats * sizeof(float), c->ctx->stream));
     // the reference never clears biquad history on retune (filter_biquad.cpp:95-97); init_FIR() only zeroes the FIR state.
     c->phase = 0; c->gen++;
@@ -1213,7 +1320,7 @@ extern "C" int msdr_chain_set_mode(msdr_chain *c, uint32_t channel, int32_t mode
             HIP_TRY(hipMemcpy(c->d_bq_state + (size_t)channel * kBqStateFloats, out, sizeof out, hipMemcpyHostToDevice));
         }
     }
-    c->h_mode[channel] = mode; c->h_tapset[channel] = tapset;
+    c->h_mode[channel] = mode; c->h_tapset[channel] = tapset; c->mode_gen++;
     if (c->d_fset) {
         const int fs = tapset * 3 + (mode == MSDR_MODE_LSB ? 0 : mode == MSDR_MODE_USB ? 1 : 2);
         HIP_TRY(hipMemcpyAsync(c->d_fset + channel, &fs, sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));

@@ -90,6 +90,12 @@ struct ChainParams {
     const void *bq_mf;         // BiquadCascadeTables<16>: 16-sample chunks
     const void *bq_mf32;       // BiquadCascadeTables<32>: 32-sample blocks (msdr_biquad_paired.hiph)
     int mf_waves;              // waves per workgroup: 4 or 8
+    // wave-stream matrix-core kernel (msdr_chain_mfw.hiph)
+    const int *mf_units;       // [workgroups][mf_nw] pairs (channel, segment); channel < 0 = idle wave
+    int mf_nw;                 // waves per workgroup (1..16)
+    unsigned long long *dbg_buf;   // diagnostic build (-DMSDR_STAMPS): per-phase cycle sums, 8 per unit
+    int dbg;                   // diagnostic bits (MSDR_DBG environment variable; 0 in normal operation)
+    float *bq_state_out;       // [channels][kBqStateFloats] cascade state after this call (ping-pong partner of bq_state)
 };
 
 }  // namespace msdr

@@ -21,6 +21,7 @@ MAX_TAPSETS = 8
 CHAIN_NO_TAP_FOLDING = 1
 CHAIN_NO_FFT = 4
 CHAIN_NO_MFMA = 8
+CHAIN_MFMA_WG = 16
 
 STATUS_ARGUMENT_ERROR, STATUS_LENGTH_ERROR, STATUS_NO_DEVICE = -1, -2, -100
 
@@ -47,7 +48,7 @@ class ChainConfig(C.Structure):
 class ChainInfo(C.Structure):
     _fields_ = [("kernel", C.c_char * 64), ("grid", C.c_uint32), ("block", C.c_uint32), ("lds_bytes", C.c_uint32),
                 ("time_segments", C.c_uint32), ("warmup", C.c_uint32), ("tile", C.c_uint32),
-                ("taps_padded", C.c_uint32)]
+                ("taps_padded", C.c_uint32), ("mfma_ksteps", C.c_uint32)]
 
 
 _lib = None
@@ -342,7 +343,8 @@ class Chain(_Instance):
         i = ChainInfo()
         _ck(self.ctx.lib.msdr_chain_get_info(self.h, C.byref(i)))
         return {"kernel": i.kernel.decode(), "grid": i.grid, "block": i.block, "lds_bytes": i.lds_bytes,
-                "time_segments": i.time_segments, "warmup": i.warmup, "tile": i.tile, "taps_padded": i.taps_padded}
+                "time_segments": i.time_segments, "warmup": i.warmup, "tile": i.tile, "taps_padded": i.taps_padded,
+                "mfma_ksteps": i.mfma_ksteps}
 
     def enable_timing(self, on=True):
         _ck(self.ctx.lib.msdr_chain_enable_timing(self.h, int(on)))

@@ -242,10 +242,16 @@ def _q15_nco(p, cycles, length=128):
     return (s / 32768.0).astype(np.float32), (c / 32768.0).astype(np.float32)
 
 
-ENGINES = {"mfma": 0, "valu": msdr.CHAIN_NO_MFMA}      # folded FIR on the matrix cores / on the fp32 VALU
+# folded FIR on the matrix cores (one wave per stream = the default, or workgroup tiles) / on the fp32 VALU
+ENGINES = {"mfw": 0, "mfma": msdr.CHAIN_MFMA_WG, "valu": msdr.CHAIN_NO_MFMA}
+ALL_ENGINES = ["mfw", "mfma", "valu"]
 
 
-@pytest.mark.parametrize("engine", ["mfma", "valu"])
+def _mf_name(engine, stages, wg_waves=4):
+    return "chain_mfw_kernel<%d>" % stages if engine == "mfw" else "chain_mfma_kernel<%d>" % wg_waves
+
+
+@pytest.mark.parametrize("engine", ALL_ENGINES)
 @pytest.mark.parametrize("period", [1, 2, 4])
 @pytest.mark.parametrize("block", [None, 333, 128, 3073])
 @pytest.mark.parametrize("mode", [orclib.LSB, orclib.USB])
@@ -261,7 +267,7 @@ def test_chain_f32_folded_ssb_vs_oracle(ctx, orc, period, block, mode, engine):
     chain = msdr.Chain(ctx, msdr.ARITH_F32, 3, hi, hq, mixer=msdr.MIXER_NCO, mode=mode, osc_i=oi, osc_q=oq, biquad_coeffs=bq,
                        flags=ENGINES[engine])
     got = run_chain(ctx, chain, x, np.float32, block)
-    assert chain.info()["kernel"] == ("chain_mfma_kernel<4>" if engine == "mfma" else "chain_fold_kernel<%d>" % period)
+    assert chain.info()["kernel"] == (_mf_name(engine, 2) if engine != "valu" else "chain_fold_kernel<%d>" % period)
     for c in range(3):
         want = orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq)
         assert rel_rms(got[c], want) < TOL, (c, rel_rms(got[c], want))
@@ -274,7 +280,7 @@ def test_chain_f32_folded_ssb_vs_oracle(ctx, orc, period, block, mode, engine):
         assert rel_rms(got2[c], orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq)) < TOL
 
 
-@pytest.mark.parametrize("engine", ["mfma", "valu"])
+@pytest.mark.parametrize("engine", ALL_ENGINES)
 @pytest.mark.parametrize("block", [None, 129, 1000])
 def test_chain_f32_folded_am_fs4_odd_blocks(ctx, orc, block, engine):
     """AM through the folded kernel (Fs/4 zero skipping) with block lengths that leave the mixer at
@@ -286,13 +292,13 @@ def test_chain_f32_folded_am_fs4_odd_blocks(ctx, orc, block, engine):
     bq = _f32_biquads(orc, 1)
     chain = msdr.Chain(ctx, msdr.ARITH_F32, 2, lp, lp, mixer=msdr.MIXER_FS4, mode=orclib.AM, biquad_coeffs=bq, flags=ENGINES[engine])
     got = run_chain(ctx, chain, x, np.float32, block)
-    assert chain.info()["kernel"] == ("chain_mfma_kernel<4>" if engine == "mfma" else "chain_fold_kernel<4>")
+    assert chain.info()["kernel"] == (_mf_name(engine, len(bq)) if engine != "valu" else "chain_fold_kernel<4>")
     cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
     for c in range(2):
         assert rel_rms(got[c], orc.chain_f32(x[c], orclib.AM, lp, lp, sin4, cos4, bq)) < TOL
 
 
-@pytest.mark.parametrize("engine", ["mfma", "valu"])
+@pytest.mark.parametrize("engine", ALL_ENGINES)
 def test_chain_f32_am_with_non_fs4_nco(ctx, orc, engine):
     """The packed-fp32 folded kernel does AM only for the exact Fs/4 pattern: a q15-rounded fs/4 table (0.99997)
     falls back to the as-written kernel there.  The matrix-core kernel takes any short-period table."""
@@ -303,7 +309,7 @@ def test_chain_f32_am_with_non_fs4_nco(ctx, orc, engine):
     chain = msdr.Chain(ctx, msdr.ARITH_F32, 2, hi, hq, mixer=msdr.MIXER_NCO, modes=np.array([orclib.AM, orclib.LSB], np.int32),
                        osc_i=oi, osc_q=oq, flags=ENGINES[engine])
     got = run_chain(ctx, chain, x, np.float32)
-    assert chain.info()["kernel"] == ("chain_mfma_kernel<4>" if engine == "mfma" else "chain_kernel<ArithF32>")
+    assert chain.info()["kernel"] == (_mf_name(engine, 0) if engine != "valu" else "chain_kernel<ArithF32>")
     for c, m in enumerate((orclib.AM, orclib.LSB)):
         assert rel_rms(got[c], orc.chain_f32(x[c], m, hi, hq, oi, oq, None)) < TOL
 
@@ -352,7 +358,7 @@ def test_chain_f32_fft_am_with_distinct_branches_falls_back(ctx, orc):
         assert rel_rms(got[c], orc.chain_f32(x[c], orclib.CW, hi, hq, sin4, cos4, None)) < TOL
 
 
-@pytest.mark.parametrize("engine", ["mfma", "valu"])
+@pytest.mark.parametrize("engine", ALL_ENGINES)
 def test_chain_f32_fft_time_segments_long_stream(ctx, orc, engine):
     rng = np.random.default_rng(6)
     n = 1 << 20
@@ -364,7 +370,7 @@ def test_chain_f32_fft_time_segments_long_stream(ctx, orc, engine):
                        flags=ENGINES[engine])
     got = run_chain(ctx, chain, x, np.float32)
     info = chain.info()
-    assert info["kernel"] == ("chain_mfma_kernel<8>" if engine == "mfma" else "chain_fft_kernel<15>") and info["time_segments"] > 1
+    assert info["kernel"] == (_mf_name(engine, 2, 8) if engine != "valu" else "chain_fft_kernel<15>") and info["time_segments"] > 1
     want = orc.chain_f32(x[0], orclib.LSB, hi, hq, oi, oq, bq)
     assert rel_rms(got[0], want) < TOL
 
@@ -372,7 +378,8 @@ def test_chain_f32_fft_time_segments_long_stream(ctx, orc, engine):
 # ---------------------------------------------------------------- fp32, matrix-core kernel ---------
 @pytest.mark.parametrize("ntaps", [1, 2, 31, 33, 64, 100, 129, 256, 512])
 @pytest.mark.parametrize("mode", [orclib.LSB, orclib.AM])
-def test_chain_f32_mfma_tap_counts(ctx, orc, ntaps, mode):
+@pytest.mark.parametrize("engine", ["mfw", "mfma"])
+def test_chain_f32_mfma_tap_counts(ctx, orc, ntaps, mode, engine):
     """The Toeplitz operand is built per tap count (halo = ntaps - 1 rounded up to 32); Fs/4 mixer, mixed block sizes,
     three channels so that rows of channels > 0 are misaligned for odd n."""
     rng = np.random.default_rng(900 + ntaps)
@@ -385,17 +392,18 @@ def test_chain_f32_mfma_tap_counts(ctx, orc, ntaps, mode):
     cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
     for n in (12288 + 8, 9001):
         x = rng.integers(-32768, 32768, (3, n)).astype(np.int16)
-        chain = msdr.Chain(ctx, msdr.ARITH_F32, 3, hi, hq, mixer=msdr.MIXER_FS4, mode=mode, biquad_coeffs=bq)
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, 3, hi, hq, mixer=msdr.MIXER_FS4, mode=mode, biquad_coeffs=bq, flags=ENGINES[engine])
         for block in (None, 4100):
             chain.reset()
             got = run_chain(ctx, chain, x, np.float32, block)
-            assert chain.info()["kernel"] == "chain_mfma_kernel<%d>" % (4 if ntaps <= 129 else 8), chain.info()
+            assert chain.info()["kernel"] == _mf_name(engine, 2, 4 if ntaps <= 129 else 8), chain.info()
             for c in range(3):
                 want = orc.chain_f32(x[c], mode, hi, hq, sin4, cos4, bq)
                 assert rel_rms(got[c], want) < TOL, (n, block, c, rel_rms(got[c], want))
 
 
-def test_chain_f32_mfma_weak_signal_keeps_fp32_accuracy(ctx, orc):
+@pytest.mark.parametrize("engine", ["mfw", "mfma"])
+def test_chain_f32_mfma_weak_signal_keeps_fp32_accuracy(ctx, orc, engine):
     """The fp16 split of the samples is a FLOATING split (11 significant bits + exact remainder), so a weak signal
     (|x| <= 40) is as accurate as a full-scale one; full-scale extremes (-32768, 32767) are exact too."""
     rng = np.random.default_rng(31)
@@ -404,13 +412,13 @@ def test_chain_f32_mfma_weak_signal_keeps_fp32_accuracy(ctx, orc):
     weak = rng.integers(-40, 41, (1, 8192)).astype(np.int16)
     rail = rng.choice(np.array([-32768, 32767, -32767, 32766, 2049, -2049], np.int16), (1, 8192))
     for x in (weak, rail):
-        chain = msdr.Chain(ctx, msdr.ARITH_F32, 1, hi, hq, mixer=msdr.MIXER_FS4, mode=orclib.USB)
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, 1, hi, hq, mixer=msdr.MIXER_FS4, mode=orclib.USB, flags=ENGINES[engine])
         got = run_chain(ctx, chain, x, np.float32)
-        assert chain.info()["kernel"] == "chain_mfma_kernel<4>"
+        assert chain.info()["kernel"] == _mf_name(engine, 0)
         assert rel_rms(got[0], orc.chain_f32(x[0], orclib.USB, hi, hq, sin4, cos4, None)) < 2e-6
 
 
-@pytest.mark.parametrize("engine", ["mfma", "valu"])
+@pytest.mark.parametrize("engine", ALL_ENGINES)
 def test_chain_f32_retune_mid_stream_keeps_cascade_state(ctx, orc, engine):
     """msdr_chain_set_mode between calls: FIR history and biquad state carry over, as in the oracle with a carried state.
     The matrix-core kernel's SSB modes fold the cascade's numerator into the FIR; entering / leaving / changing such a mode

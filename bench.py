@@ -376,7 +376,7 @@ def main():
                      "valu_peak_tflops": VALU_PEAK_TFLOPS,
                      "as_written_equivalent_tflops": round(flop_written * samples_per_step / (k_ms * 1e-3) / 1e12, 2)},
     }
-    if info["kernel"].startswith("chain_mfma"):
+    if info["kernel"].startswith("chain_mf"):
         # matrix-core kernel: the folded FIR runs as 3 v_mfma_f32_32x32x16_f16 (32768 flop each) per k-step and 1024-output
         # wave tile; the vector ALU only carries staging, demod and the IIR scan, so the valu_* fields do not apply
         r = out["roofline"]

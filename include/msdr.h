@@ -151,6 +151,40 @@ int msdr_biquad_q15_update(msdr_biquad_q15 *S, q15_t *d_data, uint32_t blockSize
 int msdr_biquad_q15_get_definition(msdr_biquad_q15 *S, uint32_t channel, int32_t definition[32]); /* filter_biquad.h:152 */
 int msdr_biquad_q15_destroy(msdr_biquad_q15 *S);
 
+/* ======================================================================================
+ * the front end in front of queue_adc (Minimal-SDR.ino:66-69, :76):
+ *   adc1 (DC-block high-pass, src/Audio/input_adc.cpp:198-212) -> amp_adc (AudioAmplifier,
+ *   src/Audio/mixer.cpp:34-47, :134-159) and AGC() (Minimal-SDR.ino:446-515), which
+ *   demodulation() runs on every block it dequeues (:534) and which re-tunes amp_adc.
+ * One instance keeps, per channel, what the reference keeps in statics: hpf_x1/hpf_y1
+ * (input_adc.h:44-45), amp_adc's multiplier, AGC_val / AGC_on (.ino:100-104) and AGC()'s
+ * 25-entry peak buffer + index.  Integer-exact (bit-for-bit with the oracle).
+ * ====================================================================================== */
+typedef struct msdr_frontend msdr_frontend;
+#define MSDR_FE_DCBLOCK 1u           /* input is raw unsigned 16-bit conversions; run the DC-block filter */
+#define MSDR_FE_AMP 2u               /* apply amp_adc's gain */
+#define MSDR_FE_AGC 4u               /* run AGC() on every 128-sample block (needs MSDR_FE_AMP to have an effect) */
+#define MSDR_FE_ALL 7u
+#define MSDR_FE_STATE_WORDS 32u      /* [0] hpf_y1 [1] hpf_x1 [2] multiplier [3] agc_idx [4] AGC_val (float bits) [5] AGC_on [6..18] agc_buffer */
+/* AudioInputAnalog() + AudioAmplifier() + the sketch's globals: hpf 0/0, AGC_val = AGC_start = 0.25 (.ino:94,:104,:385), AGC_on = 1 */
+int msdr_frontend_create(msdr_ctx *ctx, uint32_t channels, msdr_frontend **out);
+/* AudioInputAnalog::init, input_adc.cpp:60-63: hpf_x1 = first conversion << 14, hpf_y1 = 0.
+ * first_conversion: host array of `count` values, count = 1 (all channels alike) or = channels. */
+int msdr_frontend_prime(msdr_frontend *fe, const uint16_t *first_conversion, uint32_t count);
+int msdr_frontend_set_agc(msdr_frontend *fe, int on);                     /* AGC_on, .ino:100 */
+int msdr_frontend_gain(msdr_frontend *fe, float n);                       /* AGC_val = n; amp_adc.gain(n), mixer.h:75-79 */
+/* d_adc: [channels][blockSize] uint16 (MSDR_FE_DCBLOCK) or int16; d_out: [channels][blockSize] int16 (may alias d_adc).
+ * blockSize must be a multiple of 128 (AUDIO_BLOCK_SAMPLES: the AGC's update cadence), else MSDR_STATUS_LENGTH_ERROR.
+ * A zero multiplier makes AudioAmplifier transmit nothing (mixer.cpp:139-142): such blocks come out as zeros here
+ * and do not reach AGC(). */
+int msdr_frontend_update(msdr_frontend *fe, const void *d_adc, q15_t *d_out, uint32_t blockSize, uint32_t stages);
+int msdr_frontend_get_state(msdr_frontend *fe, uint32_t channel, int32_t state[MSDR_FE_STATE_WORDS]);
+int msdr_frontend_destroy(msdr_frontend *fe);
+/* AudioAmplifier as a stateless stage: multiplier as gain() computes it (mixer.h:75-79); in place.
+ * *transmitted (may be NULL) = 0 when the node would transmit nothing (multiplier 0), else 1. */
+int32_t msdr_amp_multiplier(float n);
+int msdr_amp_q15(msdr_ctx *ctx, int32_t multiplier, q15_t *d_data, uint32_t channels, uint32_t blockSize, int *transmitted);
+
 /* Stateless per-block stages. */
 /* Minimal-SDR.ino:546-558; block must start at a sample index = 0 (mod 4), as every 128-block does */
 int msdr_mix_fs4_q15(msdr_ctx *ctx, const q15_t *d_x, q15_t *d_i, q15_t *d_q, uint32_t channels, uint32_t blockSize);

@@ -9,6 +9,7 @@
 #include <type_traits>
 #include "msdr_chain_mfma.hiph"
 #include "msdr_chain_mfw.hiph"
+#include "msdr_frontend.hiph"
 #include "msdr_design.h"
 
 #include <algorithm>
@@ -18,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <string>
 #include <vector>
@@ -600,6 +602,108 @@ extern "C" int msdr_demod_f32(msdr_ctx *ctx, int mode, const int32_t *d_mode, co
     hipLaunchKernelGGL(demod_f32_kernel, dim3(grid_1d(total)), dim3(256), 0, ctx->stream, mode, d_mode, d_i, d_q, d_out, total,
                        (int)blockSize);
     return launch_check("demod_f32_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// front end: DC block + AudioAmplifier + AGC
+// ------------------------------------------------------------------------------------------------
+struct msdr_frontend {
+    msdr_ctx *ctx;
+    uint32_t channels;
+    int *d_state;          // [channels][kFeStateInts]
+};
+
+static int fe_edit(msdr_frontend *fe, const std::function<void(uint32_t, int *)> &f)
+{
+    HIP_TRY(hipStreamSynchronize(fe->ctx->stream));
+    std::vector<int> h((size_t)fe->channels * kFeStateInts);
+    HIP_TRY(hipMemcpy(h.data(), fe->d_state, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (uint32_t ch = 0; ch < fe->channels; ch++) f(ch, h.data() + (size_t)ch * kFeStateInts);
+    HIP_TRY(hipMemcpy(fe->d_state, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int32_t msdr_amp_multiplier(float n) { return fe_multiplier(n); }
+
+extern "C" int msdr_frontend_create(msdr_ctx *ctx, uint32_t channels, msdr_frontend **out)
+{
+    if (!out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "out is null");
+    *out = nullptr;
+    if (int rc = bind(ctx)) return rc;
+    if (channels == 0) return fail(MSDR_STATUS_ARGUMENT_ERROR, "channels == 0");
+    msdr_frontend *fe = new (std::nothrow) msdr_frontend();
+    if (!fe) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
+    fe->ctx = ctx; fe->channels = channels; fe->d_state = nullptr;
+    std::vector<int> h((size_t)channels * kFeStateInts, 0);
+    const float agc_start = 0.25f;                       // Minimal-SDR.ino:94
+    int bits; memcpy(&bits, &agc_start, sizeof bits);
+    for (uint32_t ch = 0; ch < channels; ch++) {
+        int *s = h.data() + (size_t)ch * kFeStateInts;
+        s[2] = fe_multiplier(agc_start); s[3] = kFeAgcBuf; s[4] = bits; s[5] = 1;
+    }
+    if (int rc = upload(ctx, h, &fe->d_state)) { delete fe; return rc; }
+    *out = fe;
+    return 0;
+}
+extern "C" int msdr_frontend_prime(msdr_frontend *fe, const uint16_t *first_conversion, uint32_t count)
+{
+    if (!fe || !first_conversion) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    if (int rc = bind(fe->ctx)) return rc;
+    if (count != 1 && count != fe->channels) return fail(MSDR_STATUS_ARGUMENT_ERROR, "count must be 1 or channels");
+    return fe_edit(fe, [&](uint32_t ch, int *s) { s[1] = (int)((uint32_t)first_conversion[count == 1 ? 0 : ch] << 14); s[0] = 0; });
+}
+extern "C" int msdr_frontend_set_agc(msdr_frontend *fe, int on)
+{
+    if (!fe) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
+    if (int rc = bind(fe->ctx)) return rc;
+    return fe_edit(fe, [&](uint32_t, int *s) { s[5] = on ? 1 : 0; });
+}
+extern "C" int msdr_frontend_gain(msdr_frontend *fe, float n)
+{
+    if (!fe) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
+    if (int rc = bind(fe->ctx)) return rc;
+    int bits; memcpy(&bits, &n, sizeof bits);
+    return fe_edit(fe, [&](uint32_t, int *s) { s[4] = bits; s[2] = fe_multiplier(n); });
+}
+extern "C" int msdr_frontend_update(msdr_frontend *fe, const void *d_adc, q15_t *d_out, uint32_t blockSize, uint32_t stages)
+{
+    if (!fe) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
+    if (int rc = bind(fe->ctx)) return rc;
+    if (blockSize == 0) return 0;
+    if (!d_adc || !d_out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    if (blockSize % 128u) return fail(MSDR_STATUS_LENGTH_ERROR, "the front end runs in AUDIO_BLOCK_SAMPLES = 128 blocks: blockSize %u is not a multiple", blockSize);
+    if (stages & ~MSDR_FE_ALL) return fail(MSDR_STATUS_ARGUMENT_ERROR, "unknown stage bits");
+    hipLaunchKernelGGL(frontend_kernel, dim3((fe->channels + 63) / 64), dim3(64), 0, fe->ctx->stream, (const unsigned short *)d_adc,
+                       (short *)d_out, fe->d_state, (int)fe->channels, (long long)blockSize, (int)stages);
+    return launch_check("frontend_kernel");
+}
+extern "C" int msdr_frontend_get_state(msdr_frontend *fe, uint32_t channel, int32_t state[MSDR_FE_STATE_WORDS])
+{
+    if (!fe || !state) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    if (int rc = bind(fe->ctx)) return rc;
+    if (channel >= fe->channels) return fail(MSDR_STATUS_ARGUMENT_ERROR, "channel out of range");
+    HIP_TRY(hipStreamSynchronize(fe->ctx->stream));
+    HIP_TRY(hipMemcpy(state, fe->d_state + (size_t)channel * kFeStateInts, kFeStateInts * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int msdr_frontend_destroy(msdr_frontend *fe)
+{
+    if (!fe) return 0;
+    if (int rc = bind(fe->ctx)) return rc;
+    (void)hipStreamSynchronize(fe->ctx->stream);
+    hipFree(fe->d_state);
+    delete fe;
+    return 0;
+}
+extern "C" int msdr_amp_q15(msdr_ctx *ctx, int32_t multiplier, q15_t *d_data, uint32_t channels, uint32_t blockSize, int *transmitted)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (transmitted) *transmitted = (multiplier != 0);
+    if (multiplier == 0 || multiplier == 65536 || channels == 0 || blockSize == 0) return 0;     // mixer.cpp:139-149
+    if (!d_data) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    const long long total = (long long)channels * blockSize;
+    hipLaunchKernelGGL(amp_q15_kernel, dim3(grid_1d(total)), dim3(256), 0, ctx->stream, (short *)d_data, total, (int)multiplier);
+    return launch_check("amp_q15_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------

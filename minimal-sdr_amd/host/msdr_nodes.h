@@ -69,6 +69,38 @@ private:
 };
 
 // ------------------------------------------------------------------------------------------------
+// AudioAmplifier -- gain stage, Q16.16 multiplier, saturating (mixer.h:67-82, mixer.cpp:34-47, :134-159).
+// amp_adc / amp_dac of the sketch (Minimal-SDR.ino:67, :73); AGC() drives amp_adc.gain() (:446-515).
+// ------------------------------------------------------------------------------------------------
+class AudioAmplifier : public AudioStream {
+public:
+    AudioAmplifier(void) : AudioStream(1, inputQueueArray), multiplier(65536) {}
+    virtual void update(void)
+    {
+        const int32_t mult = multiplier;
+        if (mult == 0) {                                       // mixer.cpp:139-142: discard, transmit nothing
+            audio_block_t *block = receiveReadOnly(0);
+            if (block) release(block);
+        } else if (mult == 65536) {                            // :143-149: unity, pass the block on untouched
+            audio_block_t *block = receiveReadOnly(0);
+            if (block) { transmit(block); release(block); }
+        } else {                                               // :150-157
+            audio_block_t *block = receiveWritable(0);
+            if (block) {
+                if (AudioGPU.context()) msdr_amp_q15(AudioGPU.context(), mult, block->data, AudioGPU.channels(), AUDIO_BLOCK_SAMPLES, nullptr);
+                transmit(block);
+                release(block);
+            }
+        }
+    }
+    void gain(float n) { multiplier = msdr_amp_multiplier(n); } // mixer.h:75-79
+
+private:
+    int32_t multiplier;
+    audio_block_t *inputQueueArray[1];
+};
+
+// ------------------------------------------------------------------------------------------------
 // AudioEffectFreqConv -- complex (I,Q) x oscillator mix in q15 (freq_conv.h:36-56, freq_conv.cpp:30-116).
 // The oscillator tables are globals of the application, exactly as in the reference (freq_conv.h:33-34).
 // Unlike the reference the kernel needs no temporary blocks, so the node cannot run out of pool memory.

@@ -22,6 +22,7 @@ CHAIN_NO_TAP_FOLDING = 1
 CHAIN_NO_FFT = 4
 CHAIN_NO_MFMA = 8
 CHAIN_MFMA_WG = 16
+FE_DCBLOCK, FE_AMP, FE_AGC, FE_ALL = 1, 2, 4, 7
 
 STATUS_ARGUMENT_ERROR, STATUS_LENGTH_ERROR, STATUS_NO_DEVICE = -1, -2, -100
 
@@ -79,6 +80,10 @@ def load_library(path=None):
         for n in ("msdr_fir_q15_process", "msdr_fir_f32_process", "msdr_biquad_df1_f32_process"):
             getattr(_lib, n).argtypes = [_p, _p, _p, C.c_uint32]
         _lib.msdr_biquad_q15_update.argtypes = [_p, _p, C.c_uint32]
+        _lib.msdr_frontend_update.argtypes = [_p, _p, _p, C.c_uint32, C.c_uint32]
+        _lib.msdr_frontend_prime.argtypes = [_p, _p, C.c_uint32]
+        _lib.msdr_frontend_get_state.argtypes = [_p, C.c_uint32, _p]
+        _lib.msdr_amp_q15.argtypes = [_p, C.c_int32, _p, C.c_uint32, C.c_uint32, _p]
     return _lib
 
 
@@ -277,6 +282,49 @@ class BiquadQ15(_Instance):
         d = np.zeros(32, np.int32)
         _ck(self.ctx.lib.msdr_biquad_q15_get_definition(self.h, C.c_uint32(channel), _hp(d)))
         return d
+
+
+class Frontend(_Instance):
+    """adc1's DC block + amp_adc + AGC(), batched over channels; state per channel as the sketch's statics."""
+    _destroy = "msdr_frontend_destroy"
+
+    def __init__(self, ctx, channels):
+        self.ctx = ctx
+        h = _p()
+        _ck(ctx.lib.msdr_frontend_create(ctx.h, C.c_uint32(channels), C.byref(h)))
+        self.h = h
+
+    def prime(self, first_conversion):
+        v = np.ascontiguousarray(np.atleast_1d(first_conversion), np.uint16)
+        _ck(self.ctx.lib.msdr_frontend_prime(self.h, _hp(v), C.c_uint32(v.size)))
+
+    def set_agc(self, on):
+        _ck(self.ctx.lib.msdr_frontend_set_agc(self.h, int(bool(on))))
+
+    def gain(self, n):
+        _ck(self.ctx.lib.msdr_frontend_gain(self.h, C.c_float(n)))
+
+    def update(self, d_adc, d_out, n, stages=FE_ALL):
+        _ck(self.ctx.lib.msdr_frontend_update(self.h, d_adc.ptr if hasattr(d_adc, "ptr") else d_adc,
+                                              d_out.ptr if hasattr(d_out, "ptr") else d_out, C.c_uint32(n), C.c_uint32(stages)))
+
+    def state(self, channel=0):
+        st = np.zeros(32, np.int32)
+        _ck(self.ctx.lib.msdr_frontend_get_state(self.h, C.c_uint32(channel), _hp(st)))
+        return st
+
+
+def amp_multiplier(n):
+    lib = load_library()
+    lib.msdr_amp_multiplier.restype = C.c_int32
+    lib.msdr_amp_multiplier.argtypes = [C.c_float]
+    return int(lib.msdr_amp_multiplier(C.c_float(n)))
+
+
+def amp_q15(ctx, multiplier, d_data, channels, n):
+    t = C.c_int(0)
+    _ck(ctx.lib.msdr_amp_q15(ctx.h, C.c_int32(multiplier), d_data.ptr, C.c_uint32(channels), C.c_uint32(n), C.byref(t)))
+    return bool(t.value)
 
 
 class Chain(_Instance):

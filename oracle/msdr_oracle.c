@@ -591,3 +591,131 @@ int orc_chain_q15_batch(const orc_chain_q15_cfg *cfg, const int32_t *mode_per_ch
     }
     return used;
 }
+
+/* ======================================================================================
+ * Row f1: front end.  See msdr_oracle.h.
+ * ====================================================================================== */
+/* input_adc.cpp:32 */
+#define ORC_COEF_HPF_DCBLOCK (1048300 << 10)
+
+/* dspinst.h:358-368 FRACMUL_SHL(x, y, z): smull t:t2 = x*y; result = (t2 << (z+1)) | (t >>(logical) (31-z)),
+ * i.e. bits [62-z : 31-z] of the 64-bit product */
+static int32_t fracmul_shl(int32_t x, int32_t y, int z)
+{
+    int64_t p = (int64_t)x * (int64_t)y;
+    uint32_t lo = (uint32_t)p, hi = (uint32_t)((uint64_t)p >> 32);
+    return (int32_t)((hi << (z + 1)) | (lo >> (31 - z)));
+}
+
+void orc_dcblock_init(orc_dcblock *s, uint16_t first_conversion)
+{
+    s->hpf_x1 = (int32_t)first_conversion << 14;     /* input_adc.cpp:60-62 */
+    s->hpf_y1 = 0;                                   /* :63 */
+}
+
+/* input_adc.cpp:198-212 */
+void orc_dcblock_update(orc_dcblock *s, const uint16_t *adc, int16_t *out, uint32_t n)
+{
+    int32_t y1 = s->hpf_y1, x1 = s->hpf_x1;
+    for (uint32_t i = 0; i < n; i++) {
+        int32_t tmp = (int32_t)adc[i] << 14;                          /* :201-202 */
+        int32_t acc = wrap_add32(wrap_add32(y1, (int32_t)(0u - (uint32_t)x1)), tmp);   /* :203-205 */
+        y1 = fracmul_shl(acc, ORC_COEF_HPF_DCBLOCK, 1);               /* :206 */
+        x1 = tmp;                                                     /* :207 */
+        out[i] = (int16_t)ssat16(y1 >> 14);                           /* :208 signed_saturate_rshift(hpf_y1, 16, 14) */
+    }
+    s->hpf_y1 = y1; s->hpf_x1 = x1;
+}
+
+/* mixer.h:75-79 */
+int32_t orc_amp_multiplier(float n)
+{
+    if (n > 32767.0f) n = 32767.0f;
+    else if (n < -32767.0f) n = -32767.0f;
+    return (int32_t)(n * 65536.0f);
+}
+
+/* mixer.cpp:134-159 with applyGain :34-47 (smulwb/smulwt = (mult * s16) >> 16, then ssat 16) */
+int orc_amp_update(int32_t mult, int16_t *data, uint32_t n)
+{
+    if (mult == 0) return 0;                       /* :139-142 nothing transmitted */
+    if (mult == 65536) return 1;                   /* :143-149 passed on unchanged */
+    for (uint32_t i = 0; i < n; i++) data[i] = (int16_t)ssat16(mulw16(mult, data[i]));
+    return 1;
+}
+
+void orc_agc_init(orc_agc *a)
+{
+    memset(a->agc_buffer, 0, sizeof a->agc_buffer);
+    a->agc_idx = ORC_AGCBUF_SIZE;                  /* Minimal-SDR.ino:451 */
+    a->AGC_val = 0.25f;                            /* :94, :104 */
+    a->AGC_on = 1;                                 /* :100 */
+    a->multiplier = orc_amp_multiplier(a->AGC_val);/* :385 */
+}
+
+/* __SSUB16 (cmsis_gcc.h:1684): per halfword a - b, GE[1:0]/GE[3:2] set when the (exact) signed result >= 0;
+ * __SEL (cmsis_gcc.h:2022): per byte, a where GE is set, else b.  Returns the selected word. */
+static uint32_t ssub16_sel(uint32_t cmp_a, uint32_t cmp_b, uint32_t sel_a, uint32_t sel_b)
+{
+    const int ge_lo = (int32_t)(int16_t)(cmp_a & 0xFFFF) - (int32_t)(int16_t)(cmp_b & 0xFFFF) >= 0;
+    const int ge_hi = (int32_t)(int16_t)(cmp_a >> 16) - (int32_t)(int16_t)(cmp_b >> 16) >= 0;
+    return ((ge_lo ? sel_a : sel_b) & 0x0000FFFFu) | ((ge_hi ? sel_a : sel_b) & 0xFFFF0000u);
+}
+
+/* Minimal-SDR.ino:446-515.  All arithmetic as the source states it under standard C++: `int` words for the packed
+ * min/max (so the odd-sample halves start at -1 / 0, :457-458), abs() on the whole word (:475-476), float for
+ * f / fagc / AGC_val, double for the comparisons against 1.3, 0.1, 0.6 ... (unsuffixed literals).  The store to
+ * agc_buffer[-1] on every 26th call (:480-481 decrement, then test) is outside the array: it is dropped here. */
+void orc_agc_block(orc_agc *a, const int16_t *block)
+{
+    if (!a->AGC_on) return;
+    int32_t minv = 32767, maxv = -32767;
+    for (int i = 0; i < ORC_BLOCK / 2; i++) {
+        uint32_t data = (uint32_t)(uint16_t)block[2 * i] | ((uint32_t)(uint16_t)block[2 * i + 1] << 16);
+        maxv = (int32_t)ssub16_sel((uint32_t)maxv, data, (uint32_t)maxv, data);
+        minv = (int32_t)ssub16_sel(data, (uint32_t)minv, (uint32_t)minv, data);
+    }
+    maxv = (int32_t)ssub16_sel((uint32_t)maxv, (uint32_t)(maxv >> 16), (uint32_t)maxv, (uint32_t)(maxv >> 16));   /* :470-471 */
+    minv = (int32_t)ssub16_sel((uint32_t)(minv >> 16), (uint32_t)minv, (uint32_t)minv, (uint32_t)(minv >> 16));   /* :472-473 */
+    minv = (int32_t)(minv < 0 ? 0u - (uint32_t)minv : (uint32_t)minv);      /* abs(), :475 */
+    maxv = (int32_t)(maxv < 0 ? 0u - (uint32_t)maxv : (uint32_t)maxv);      /* :476 */
+    uint16_t absmax = (uint16_t)ssub16_sel((uint32_t)maxv, (uint32_t)minv, (uint32_t)maxv, (uint32_t)minv);       /* :477-478 */
+
+    --a->agc_idx;                                                    /* :480 */
+    if (a->agc_idx >= 0) a->agc_buffer[a->agc_idx] = (int16_t)absmax;
+    if (a->agc_idx < 0) a->agc_idx = ORC_AGCBUF_SIZE;                /* :481 */
+
+    int m = 0;
+    for (int i = 0; i < ORC_AGCBUF_SIZE; i++) m += a->agc_buffer[i];
+    int d = m / ORC_AGCBUF_SIZE;                                     /* :485 */
+    const float x = 16000;
+    float f = x / (float)d;                                          /* :488 (d == 0 -> +inf) */
+    float AGC_val = a->AGC_val;
+    int set = 0;
+    if ((double)f > 1.3) {
+        float fagc = AGC_val + (AGC_val * f / 1500);                 /* :489 */
+        if (fagc < 40.0f) { AGC_val = fagc; set = 1; }               /* :490-493, AGC_Max :95 */
+    } else if ((double)AGC_val > 0.1) {
+        if ((double)f < 0.6) { AGC_val = AGC_val - (AGC_val * f / 50); set = 1; }
+        else if ((double)f < 0.7) { AGC_val = AGC_val - (AGC_val * f / 200); set = 1; }
+        else if ((double)f < 0.8) { AGC_val = AGC_val - (AGC_val * f / 2000); set = 1; }
+        else if ((double)f < 0.9) { AGC_val = AGC_val - (AGC_val * f / 4000); set = 1; }
+    }
+    if (set) { a->AGC_val = AGC_val; a->multiplier = orc_amp_multiplier(AGC_val); }
+}
+
+void orc_frontend_init(orc_frontend *f, uint16_t first_conversion)
+{
+    orc_dcblock_init(&f->dc, first_conversion);
+    orc_agc_init(&f->agc);
+}
+
+void orc_frontend_run(orc_frontend *f, const uint16_t *adc, int16_t *out, uint32_t n_blocks)
+{
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        int16_t *o = out + (size_t)b * ORC_BLOCK;
+        orc_dcblock_update(&f->dc, adc + (size_t)b * ORC_BLOCK, o, ORC_BLOCK);
+        if (!orc_amp_update(f->agc.multiplier, o, ORC_BLOCK)) { memset(o, 0, ORC_BLOCK * sizeof(int16_t)); continue; }
+        orc_agc_block(&f->agc, o);
+    }
+}

@@ -163,6 +163,37 @@ int orc_chain_q15_batch(const orc_chain_q15_cfg *cfg, const int32_t *mode_per_ch
                         const int16_t *x, int16_t *audio, uint32_t channels,
                         uint32_t n_blocks, int threads);
 
+/* ======================================================================================
+ * Row f1: the front end in front of queue_adc (Minimal-SDR.ino:66-69, 76):
+ *   adc1 (DC-block high-pass, src/Audio/input_adc.cpp:198-212) -> amp_adc (AudioAmplifier,
+ *   src/Audio/mixer.cpp:34-47, :134-159, gain() mixer.h:75-79) -> queue_adc, and AGC()
+ *   (Minimal-SDR.ino:446-515), which demodulation() runs on every block it dequeues (:534).
+ * UNPINNED: input_adc.cpp / mixer.cpp need the un-vendored Teensyduino core and ARM inline asm
+ * (dspinst.h smulwb/ssat/smull), AGC() needs __SSUB16/__SEL (ARM-only in cmsis_gcc.h:1684,:2022).
+ * ====================================================================================== */
+typedef struct { int32_t hpf_y1, hpf_x1; } orc_dcblock;                 /* input_adc.h:44-45 */
+void orc_dcblock_init(orc_dcblock *s, uint16_t first_conversion);          /* input_adc.cpp:60-63 */
+/* adc: raw unsigned 16-bit conversions; out: the block AudioInputAnalog transmits */
+void orc_dcblock_update(orc_dcblock *s, const uint16_t *adc, int16_t *out, uint32_t n);
+int32_t orc_amp_multiplier(float gain);                                    /* AudioAmplifier::gain, mixer.h:75-79 */
+/* AudioAmplifier::update, mixer.cpp:134-159: returns 0 when nothing is transmitted (multiplier 0), else 1; in place */
+int orc_amp_update(int32_t multiplier, int16_t *data, uint32_t n);
+#define ORC_AGCBUF_SIZE 25                                                 /* Minimal-SDR.ino:445 */
+typedef struct {
+    int16_t agc_buffer[ORC_AGCBUF_SIZE];   /* static in AGC(), zero initialised */
+    int32_t agc_idx;                       /* static, starts at AGCBUF_SIZE */
+    float AGC_val;                         /* Minimal-SDR.ino:104, AGC_start = 0.25f (:94) */
+    int32_t AGC_on;                        /* :100 */
+    int32_t multiplier;                    /* amp_adc's, set by amp_adc.gain(AGC_val) (:385, :492 ...) */
+} orc_agc;
+void orc_agc_init(orc_agc *a);
+void orc_agc_block(orc_agc *a, const int16_t *block);   /* AGC(p_adc) on one 128-sample block */
+typedef struct { orc_dcblock dc; orc_agc agc; } orc_frontend;
+void orc_frontend_init(orc_frontend *f, uint16_t first_conversion);
+/* n_blocks blocks of ORC_BLOCK raw conversions -> the blocks demodulation() reads.  The gain AGC() sets while looking at
+ * block k applies from block k+1 on (the reference has the record queue in between; one block is the shortest delay). */
+void orc_frontend_run(orc_frontend *f, const uint16_t *adc, int16_t *out, uint32_t n_blocks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@
 //     kernel-function API: Fs/4 mix -> arm_fir_fast_q15 x2 -> demod switch.
 //   graph B: source -> AudioSDRDemodulator (fused kernel, biquads inside) -> capture
 //   graph C: two sources -> AudioEffectFreqConv -> two captures
+//   graph D: source -> AudioAmplifier (amp_adc / amp_dac, mixer.cpp:134-159) -> capture
 // Exit code 0 = every sample bit-exact against the oracle.  `--no-gpu` checks the failure path only.
 #include <cstdio>
 #include <cstdlib>
@@ -65,6 +66,13 @@ static AudioConnection patchC2(src_q, 0, freqconv, 1);
 static AudioConnection patchC3(freqconv, 0, cap_i, 0);
 static AudioConnection patchC4(freqconv, 1, cap_q, 0);
 
+// ---- graph D ---------------------------------------------------------------------------------
+static TestSource src_d;
+static AudioAmplifier amp_d;
+static AudioRecordQueue cap_d;
+static AudioConnection patchD1(src_d, amp_d);
+static AudioConnection patchD2(amp_d, cap_d);
+
 static int mode = ORC_AM;
 static msdr_fir_q15 *FIR_I, *FIR_Q;
 static int16_t *d_I, *d_Q, *d_If, *d_Qf;
@@ -122,7 +130,7 @@ int main(int argc, char **argv)
     CHECK(msdr_fir_q15_create(ctx, 102, FIR_AM_coeffs, CH, &FIR_I) == 0, "FIR_I");
     CHECK(msdr_fir_q15_create(ctx, 102, FIR_AM_coeffs, CH, &FIR_Q) == 0, "FIR_Q");
     for (int16_t **p : {&d_I, &d_Q, &d_If, &d_Qf}) msdr_malloc(ctx, AudioGPU.block_bytes(), (void **)p);
-    queue_adc.begin(); capture_a.begin(); capture_b.begin(); cap_i.begin(); cap_q.begin();
+    queue_adc.begin(); capture_a.begin(); capture_b.begin(); cap_i.begin(); cap_q.begin(); cap_d.begin();
 
     // fused node: same chain, biquads inside
     int32_t lp[5], nt[5];
@@ -193,6 +201,19 @@ int main(int argc, char **argv)
     CHECK(cap_i.available() == 0 && cap_q.available() == 0, "freq_conv transmitted with a missing input");
     CHECK(AudioMemoryUsage() == 0, "blocks leaked after graph C: %d", (int)AudioMemoryUsage());
 
+    // ---- graph D: AudioAmplifier: gain, unity pass-through, zero gain transmits nothing (mixer.cpp:139-157) ----
+    for (float g : {0.37f, 1.0f, 3.0f, -1.0f, 0.0f}) {
+        amp_d.gain(g);
+        for (auto &v : xi) v = (int16_t)((rand() % 65536) - 32768);
+        src_d.next = xi.data();
+        AudioStream::update_all();
+        std::vector<int16_t> w = xi;
+        const int sent = orc_amp_update(orc_amp_multiplier(g), w.data(), (uint32_t)w.size());
+        if (!sent) CHECK(cap_d.available() == 0, "AudioAmplifier with zero gain transmitted a block");
+        else { fetch(cap_d, gi); CHECK(gi == w, "graph D (AudioAmplifier gain %g) differs from the oracle", (double)g); }
+    }
+    CHECK(AudioMemoryUsage() == 0, "blocks leaked after graph D: %d", (int)AudioMemoryUsage());
+
     // pool exhaustion: a node that cannot allocate drops the tick's data, nothing crashes (record_queue.cpp:91-92)
     AudioMemory(1);
     adc1.next = x.data(); adc_b.next = x.data();
@@ -201,6 +222,6 @@ int main(int argc, char **argv)
 
     AudioGPU.synchronize();
     msdr_fir_q15_destroy(FIR_I); msdr_fir_q15_destroy(FIR_Q);
-    printf("test_graph: %s\n", fails ? "FAILED" : "OK (graphs A, B, C bit-exact vs oracle)");
+    printf("test_graph: %s\n", fails ? "FAILED" : "OK (graphs A, B, C, D bit-exact vs oracle)");
     return fails ? 1 : 0;
 }

@@ -68,6 +68,19 @@ class ChainF32State(C.Structure):
     _fields_ = [("hist_i", _p), ("hist_q", _p), ("bq_state", C.c_float * 16), ("n0", C.c_uint64)]
 
 
+class DcBlock(C.Structure):
+    _fields_ = [("hpf_y1", C.c_int32), ("hpf_x1", C.c_int32)]
+
+
+class Agc(C.Structure):
+    _fields_ = [("agc_buffer", C.c_int16 * 25), ("agc_idx", C.c_int32), ("AGC_val", C.c_float), ("AGC_on", C.c_int32),
+                ("multiplier", C.c_int32)]
+
+
+class Frontend(C.Structure):
+    _fields_ = [("dc", DcBlock), ("agc", Agc)]
+
+
 class Oracle:
     """Thin, numpy-in/numpy-out face of liboracle.so."""
 
@@ -194,6 +207,45 @@ class Oracle:
         return y
 
     # ---- A9 -----------------------------------------------------------------------------
+    # ---- row f1: front end (DC block, AudioAmplifier, AGC) ----
+    def frontend_new(self, first_conversion=0, agc_on=True, gain=None):
+        f = Frontend()
+        self.lib.orc_frontend_init(C.byref(f), C.c_uint16(int(first_conversion)))
+        f.agc.AGC_on = 1 if agc_on else 0
+        if gain is not None:
+            f.agc.AGC_val = gain
+            f.agc.multiplier = self.amp_multiplier(gain)
+        return f
+
+    def amp_multiplier(self, gain):
+        self.lib.orc_amp_multiplier.restype = C.c_int32
+        self.lib.orc_amp_multiplier.argtypes = [C.c_float]
+        return int(self.lib.orc_amp_multiplier(C.c_float(gain)))
+
+    def frontend_run(self, f, adc):
+        adc = np.ascontiguousarray(adc, np.uint16)
+        assert adc.size % BLOCK == 0
+        out = np.empty(adc.size, np.int16)
+        self.lib.orc_frontend_run(C.byref(f), _ptr(adc), _ptr(out), C.c_uint32(adc.size // BLOCK))
+        return out
+
+    def dcblock(self, st, adc):
+        adc = np.ascontiguousarray(adc, np.uint16)
+        out = np.empty(adc.size, np.int16)
+        self.lib.orc_dcblock_update(C.byref(st), _ptr(adc), _ptr(out), C.c_uint32(adc.size))
+        return out
+
+    def amp_update(self, mult, data):
+        d = np.ascontiguousarray(data, np.int16).copy()
+        self.lib.orc_amp_update.restype = C.c_int
+        ok = self.lib.orc_amp_update(C.c_int32(int(mult)), _ptr(d), C.c_uint32(d.size))
+        return (d if ok else None)
+
+    def agc_block(self, a, block):
+        b = np.ascontiguousarray(block, np.int16)
+        assert b.size == BLOCK
+        self.lib.orc_agc_block(C.byref(a), _ptr(b))
+
     def calc_fir_coeffs(self, n, fc, astop=70.0, ftype=0, dfc=0.0, fs=24000.0, pi_double=False, room=None):
         self.lib.orc_set_pi_double(int(pi_double))
         buf = np.zeros(room or (2 * n + 8), np.int16)

@@ -27,4 +27,4 @@ def test_reference_graph_bit_exact_on_gpu():
     exe = _build()
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "OK (graphs A, B, C bit-exact vs oracle)" in out.stdout
+    assert "OK (graphs A, B, C, D bit-exact vs oracle)" in out.stdout

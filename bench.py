@@ -208,12 +208,79 @@ def cpu_baseline_q15(wl, x_host, gpu_first, target_s=12.0):
                       % (xs.shape[0], per_row, passes, total_dt)}, bad, m
 
 
+def bench_frontend(args, torch, msdr, dev, rank, local_rank, world, dist):
+    """Row f1: DC block + AudioAmplifier + AGC over 4096 channels x 2^18 raw conversions (integer, bit-exact).  One lane per
+    channel (the recurrences are exact only in order), so this is latency-bound by construction; reported for completeness."""
+    ch, n = args.channels or 4096, args.samples or (1 << 18)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx = msdr.Context(local_rank, stream.cuda_stream)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11 + rank)
+    t = torch.arange(n, device=dev, dtype=torch.float32)
+    x = (32768 + 6000 * torch.cos(t * (2 * math.pi * 6000.0 / FS))[None, :] * (0.3 + torch.rand((ch, 1), device=dev, generator=g))
+         + torch.randint(-60, 61, (ch, n), device=dev, generator=g)).clamp(0, 65535).to(torch.int32)
+    x = (x - 65536 * (x >= 32768).to(torch.int32)).to(torch.int16)          # the same 16 bits, viewed as int16 storage
+    y = torch.empty((ch, n), dtype=torch.int16, device=dev)
+    fe = msdr.Frontend(ctx, ch)
+    fe.prime(np.uint16(32768))
+    torch.cuda.synchronize(dev)
+    fe.update(x.data_ptr(), y.data_ptr(), n)
+    torch.cuda.synchronize(dev)
+    first = y[:8].cpu().numpy() if rank == 0 else None
+    for _ in range(max(0, args.warmup - 1)):
+        fe.update(x.data_ptr(), y.data_ptr(), n)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fe.update(x.data_ptr(), y.data_ptr(), n)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import msdr_dist
+        dt = msdr_dist.max_over_ranks(dt, dev)
+    if rank != 0:
+        return
+    value = world * ch * n * args.steps / dt / 1e6
+    ms = dt / args.steps * 1e3
+    out = {"metric": "Msamples/s through the front end (DC block -> AudioAmplifier -> AGC); achieved HBM GB/s vs peak",
+           "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "q15 (uint16 in, int16 out, int32/int64 recurrences)", "data": "synthetic",
+           "config": {"workload": "fe: %d channels x %d raw conversions, DC block + gain + AGC per 128-sample block" % (ch, n),
+                      "channels_per_gpu": ch, "samples_per_channel_per_step": n, "kernel": "frontend_kernel"},
+           "roofline": {"bound": "hbm", "achieved": round(4.0 * ch * n / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(4.0 * ch * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "note": "one lane per channel: serial integer recurrences, latency-bound by construction"}}
+    if not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orclib
+        orc = orclib.Oracle()
+        xs = x[:8, :1 << 16].cpu().numpy().view(np.uint16)
+        t1 = time.perf_counter()
+        bad = 0
+        for c in range(xs.shape[0]):
+            f = orc.frontend_new(first_conversion=32768)
+            want = orc.frontend_run(f, xs[c])
+            bad += int((want != first[c, :xs.shape[1]]).sum())
+        cdt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(xs.size / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                               "sample": "%d channels x %d samples of the same input (oracle/msdr_oracle.c orc_frontend_run)" % xs.shape}
+        out["parity"] = {"mismatching_samples": bad, "tolerance": 0}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "fe"],
+                    help="c2..c5 = BASELINE.json configs[1..4]; fe = the front end (SURVEY 8 f1) on the c3 shape")
     ap.add_argument("--samples", type=int, default=0, help="override samples per channel per step")
     ap.add_argument("--channels", type=int, default=0, help="override channels per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -246,6 +313,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.workload == "fe":
+        return bench_frontend(args, torch, msdr, dev, rank, local_rank, world, dist)
     wl = workload(args.workload, msdr, rank, args.osc_period)
     if args.samples:
         wl["n"] = args.samples

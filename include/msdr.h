@@ -185,6 +185,23 @@ int msdr_frontend_destroy(msdr_frontend *fe);
 int32_t msdr_amp_multiplier(float n);
 int msdr_amp_q15(msdr_ctx *ctx, int32_t multiplier, q15_t *d_data, uint32_t channels, uint32_t blockSize, int *transmitted);
 
+/* ======================================================================================
+ * synchronous AM -- the PLL branch of the demod switch on Teensy 3.5/3.6
+ * (Minimal-SDR.ino:631-688).  State per channel = the statics fil_out, omega2, phzerror
+ * (:643-645).  d_mode: device int32 [channels] or NULL; with a mode array only SYNCAM
+ * channels run the PLL, the others pass d_I through.  d_out may alias d_I.
+ * sinf/cosf/atan2f are evaluated correctly rounded (see oracle/msdr_oracle.h, row f2).
+ * In the fused Q15 chain, MSDR_CHAIN_SYNCAM_PLL selects this branch for SYNCAM channels
+ * (default: SYNCAM demodulates like AM, the Teensy 3.2 build, .ino:618-627).
+ * ====================================================================================== */
+typedef struct msdr_syncam msdr_syncam;
+int msdr_syncam_create(msdr_ctx *ctx, uint32_t channels, msdr_syncam **out);
+int msdr_syncam_q15(msdr_syncam *S, const int32_t *d_mode, const q15_t *d_I, const q15_t *d_Q, q15_t *d_out, uint32_t blockSize);
+int msdr_syncam_reset(msdr_syncam *S);
+int msdr_syncam_get_state(msdr_syncam *S, uint32_t channel, float state[3]);    /* fil_out, omega2, phzerror */
+void msdr_syncam_constants(float c[4]);                                         /* omega_min, omega_max, g1, g2 (:639-642) */
+int msdr_syncam_destroy(msdr_syncam *S);
+
 /* Stateless per-block stages. */
 /* Minimal-SDR.ino:546-558; block must start at a sample index = 0 (mod 4), as every 128-block does */
 int msdr_mix_fs4_q15(msdr_ctx *ctx, const q15_t *d_x, q15_t *d_i, q15_t *d_q, uint32_t channels, uint32_t blockSize);
@@ -243,6 +260,7 @@ typedef struct {
 #define MSDR_CHAIN_NO_TAP_FOLDING 1u /* F32: keep mixer and FIR pair as separate arithmetic steps (as written) */
 #define MSDR_CHAIN_NO_FFT 4u         /* F32: never use the overlap-save FFT kernel (long FIRs stay sliding dot products) */
 #define MSDR_CHAIN_NO_MFMA 8u        /* F32: never run the folded FIR on the matrix cores (split-fp16 MFMA kernel) */
+#define MSDR_CHAIN_SYNCAM_PLL 32u    /* Q15: SYNCAM channels run the PLL demodulator (.ino:631-688) instead of the AM branch */
 #define MSDR_CHAIN_MFMA_WG 16u       /* F32: matrix-core kernel with workgroup tiles (msdr_chain_mfma.hiph) instead of one wave per stream */
 
 typedef struct msdr_chain msdr_chain;

@@ -707,6 +707,82 @@ extern "C" int msdr_amp_q15(msdr_ctx *ctx, int32_t multiplier, q15_t *d_data, ui
 }
 
 // ------------------------------------------------------------------------------------------------
+// synchronous AM PLL
+// ------------------------------------------------------------------------------------------------
+struct msdr_syncam {
+    msdr_ctx *ctx;
+    uint32_t channels;
+    float *d_state;        // [channels][4]
+};
+
+extern "C" void msdr_syncam_constants(float c[4])
+{
+    // the initialisers of Minimal-SDR.ino:637-642 under C's usual arithmetic conversions (PI = Arduino.h's double literal)
+    const double PI_ = 3.1415926535897932384626433832795;
+    const float omegaN = 400.0, zeta = 0.45;
+    const int SAMPLE_RATE_ = 24000;
+    c[0] = (float)(2.0 * PI_ * -4000.0 / SAMPLE_RATE_);
+    c[1] = (float)(2.0 * PI_ * 4000.0 / SAMPLE_RATE_);
+    const float g1 = (float)(1.0 - std::exp(-2.0 * (double)omegaN * (double)zeta / SAMPLE_RATE_));
+    const float e_arg = -omegaN * zeta / (float)SAMPLE_RATE_;
+    const float c_arg = omegaN / (float)SAMPLE_RATE_ * sqrtf((float)(1.0 - (double)(zeta * zeta)));
+    c[2] = g1;
+    c[3] = (float)(-(double)g1 + 2.0 * (1 - std::exp((double)e_arg) * (double)cosf(c_arg)));
+}
+extern "C" int msdr_syncam_create(msdr_ctx *ctx, uint32_t channels, msdr_syncam **out)
+{
+    if (!out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "out is null");
+    *out = nullptr;
+    if (int rc = bind(ctx)) return rc;
+    if (channels == 0) return fail(MSDR_STATUS_ARGUMENT_ERROR, "channels == 0");
+    msdr_syncam *S = new (std::nothrow) msdr_syncam();
+    if (!S) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
+    S->ctx = ctx; S->channels = channels; S->d_state = nullptr;
+    if (int rc = dzalloc(ctx, (size_t)channels * 4, &S->d_state)) { delete S; return rc; }
+    *out = S;
+    return 0;
+}
+extern "C" int msdr_syncam_q15(msdr_syncam *S, const int32_t *d_mode, const q15_t *d_I, const q15_t *d_Q, q15_t *d_out, uint32_t blockSize)
+{
+    if (!S) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
+    if (int rc = bind(S->ctx)) return rc;
+    if (blockSize == 0) return 0;
+    if (!d_I || !d_Q || !d_out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    SyncamConst k;
+    float c[4];
+    msdr_syncam_constants(c);
+    k.omega_min = c[0]; k.omega_max = c[1]; k.g1 = c[2]; k.g2 = c[3];
+    hipLaunchKernelGGL(syncam_pll_kernel, dim3((S->channels + 63) / 64), dim3(64), 0, S->ctx->stream, (const short *)d_I, (const short *)d_Q,
+                       (short *)d_out, S->d_state, (const int *)d_mode, (int)S->channels, (long long)blockSize, k);
+    return launch_check("syncam_pll_kernel");
+}
+extern "C" int msdr_syncam_reset(msdr_syncam *S)
+{
+    if (!S) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
+    if (int rc = bind(S->ctx)) return rc;
+    HIP_TRY(hipMemsetAsync(S->d_state, 0, (size_t)S->channels * 4 * sizeof(float), S->ctx->stream));
+    return 0;
+}
+extern "C" int msdr_syncam_get_state(msdr_syncam *S, uint32_t channel, float state[3])
+{
+    if (!S || !state) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    if (int rc = bind(S->ctx)) return rc;
+    if (channel >= S->channels) return fail(MSDR_STATUS_ARGUMENT_ERROR, "channel out of range");
+    HIP_TRY(hipStreamSynchronize(S->ctx->stream));
+    HIP_TRY(hipMemcpy(state, S->d_state + (size_t)channel * 4, 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int msdr_syncam_destroy(msdr_syncam *S)
+{
+    if (!S) return 0;
+    if (int rc = bind(S->ctx)) return rc;
+    (void)hipStreamSynchronize(S->ctx->stream);
+    hipFree(S->d_state);
+    delete S;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused chain
 // ------------------------------------------------------------------------------------------------
 struct msdr_chain {
@@ -761,6 +837,9 @@ struct msdr_chain {
     std::vector<uint64_t> dh_gen;
     uint64_t gen;                                         // process calls so far + 1
     msdr_biquad_q15 *nodes[2];
+    msdr_syncam *pll;                 // Q15 + MSDR_CHAIN_SYNCAM_PLL: the PLL demodulator of SYNCAM channels and its Q scratch
+    int16_t *d_pll_q;
+    size_t pll_q_cap;
     msdr_chain_info info;
     // optional per-launch timing of the main kernel
     bool timing;
@@ -778,6 +857,8 @@ static void chain_free(msdr_chain *c)
     hipFree(c->d_fft_h); hipFree(c->d_fft_tw); hipFree(c->d_bq_fft); hipFree(c->d_mf_tab); hipFree(c->d_bq_mf); hipFree(c->d_bq_mf32);
     hipFree(c->d_bq_state_alt); hipFree(c->d_units);
     for (int k = 0; k < 2; k++) if (c->nodes[k]) msdr_biquad_q15_destroy(c->nodes[k]);
+    if (c->pll) msdr_syncam_destroy(c->pll);
+    hipFree(c->d_pll_q);
     for (auto &e : c->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete c;
 }
@@ -832,6 +913,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->gen = 1; c->dh_cache.resize(c->channels); c->dh_gen.assign(c->channels, 0);
     c->flags = cfg->flags; c->mfw_nw = 0; c->mfw_waves_per_cu = 0; c->d_bq_state_alt = nullptr; c->d_units = nullptr; c->units_cap = 0;
     c->mode_gen = 1; c->units_mode_gen = 0; c->units_nseg = 0; c->units_wgs = 0;
+    c->pll = nullptr; c->d_pll_q = nullptr; c->pll_q_cap = 0;
     if (f32) {
         c->h_coef_i.resize(c->tapsets); c->h_coef_q.resize(c->tapsets);
         for (uint32_t s = 0; s < c->tapsets; s++) {
@@ -1164,6 +1246,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         for (uint32_t s = 0; s < cfg->node_stages[k] && !rc; s++)
             rc = msdr_biquad_q15_set_coefficients(c->nodes[k], s, cfg->node_coefs[k] + 5 * s);
     }
+    if (!rc && !f32 && (cfg->flags & MSDR_CHAIN_SYNCAM_PLL)) rc = msdr_syncam_create(ctx, c->channels, &c->pll);
     if (rc) { chain_free(c); return rc; }
     *out = c;
     return 0;
@@ -1199,6 +1282,20 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             const int m = c->h_mode[ch];
             if (m != MSDR_MODE_LSB && m != MSDR_MODE_USB && !c->fft_am_ok[c->h_tapset[ch]]) { use_fft = false; break; }
         }
+    bool pll_active = false;
+    if (c->pll) {
+        for (int m : c->h_mode) if (m == MSDR_MODE_SYNCAM) { pll_active = true; break; }
+        if (pll_active) {
+            const size_t need = (size_t)c->channels * n_samples;
+            if (need > c->pll_q_cap) {
+                HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+                hipFree(c->d_pll_q); c->d_pll_q = nullptr; c->pll_q_cap = 0;
+                HIP_TRY(hipMalloc((void **)&c->d_pll_q, need * sizeof(int16_t)));
+                c->pll_q_cap = need;
+            }
+            p.syncam_q = c->d_pll_q;
+        }
+    }
     const bool use_mf = f32 && c->mf_ok;
     const bool use_mfw = use_mf && c->mfw_nw > 0 && !(c->flags & MSDR_CHAIN_MFMA_WG);
     if (use_mf) use_fft = false;
@@ -1332,6 +1429,9 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     if (int rc = launch_check("chain_kernel")) return rc;
     if (e0) { HIP_TRY(hipEventRecord(e1, c->ctx->stream)); c->events.emplace_back(e0, e1); }
 
+    if (pll_active)            // SYNCAM channels: I (in d_audio) and Q (scratch) -> PLL demodulator -> audio, before the biquad nodes
+        if (int rc = msdr_syncam_q15(c->pll, c->d_mode, (const q15_t *)d_audio, c->d_pll_q, (q15_t *)d_audio, (uint32_t)n_samples)) return rc;
+
     if (c->nnodes == 2) {      // biquad1_dac -> biquad2_dac in one pass over the audio
         hipLaunchKernelGGL((biquad_teensy_kernel<2>), dim3((c->channels + 63) / 64), dim3(64), 0, c->ctx->stream, (short *)d_audio,
                            c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);
@@ -1365,6 +1465,7 @@ extern "C" int msdr_chain_reset(msdr_chain *c)
     if (c->d_bq_state_alt) HIP_TRY(hipMemsetAsync(c->d_bq_state_alt, 0, (size_t)c->channels * kBqStateFloats * sizeof(float), c->ctx->stream));
     if (c->d_bq_state) HIP_TRY(hipMemsetAsync(c->d_bq_state, 0, (size_t)c->channels * kBqStateFloats * sizeof(float), c->ctx->stream));
     // the reference never clears biquad history on retune (filter_biquad.cpp:95-97); init_FIR() only zeroes the FIR state.
+    if (c->pll) if (int rc = msdr_syncam_reset(c->pll)) return rc;
     c->phase = 0; c->gen++;
     return 0;
 }

@@ -72,6 +72,7 @@ struct ChainParams {
     int nstages;               // F32 biquad stages
     const BiquadCascadeTables<kChainR> *bq;
     float *bq_state;           // [channels][kBqStateFloats]
+    short *syncam_q;           // Q15, MSDR_CHAIN_SYNCAM_PLL: [channels][n] post-FIR Q of SYNCAM channels (their I goes to `out`); else null
     // folded F32 kernel (mixer folded into the taps; see DESIGN.md "Tap folding")
     const float *ftaps;        // [fsets][P rotations][steps][PE rows][2][2] folded tap pairs, in_scale included
     const int *chan_fset;      // [channels] folded-set index

@@ -22,6 +22,7 @@ CHAIN_NO_TAP_FOLDING = 1
 CHAIN_NO_FFT = 4
 CHAIN_NO_MFMA = 8
 CHAIN_MFMA_WG = 16
+CHAIN_SYNCAM_PLL = 32
 FE_DCBLOCK, FE_AMP, FE_AGC, FE_ALL = 1, 2, 4, 7
 
 STATUS_ARGUMENT_ERROR, STATUS_LENGTH_ERROR, STATUS_NO_DEVICE = -1, -2, -100
@@ -84,6 +85,10 @@ def load_library(path=None):
         _lib.msdr_frontend_prime.argtypes = [_p, _p, C.c_uint32]
         _lib.msdr_frontend_get_state.argtypes = [_p, C.c_uint32, _p]
         _lib.msdr_amp_q15.argtypes = [_p, C.c_int32, _p, C.c_uint32, C.c_uint32, _p]
+        _lib.msdr_syncam_q15.argtypes = [_p, _p, _p, _p, _p, C.c_uint32]
+        _lib.msdr_syncam_get_state.argtypes = [_p, C.c_uint32, _p]
+        _lib.msdr_syncam_constants.argtypes = [_p]
+        _lib.msdr_syncam_constants.restype = None
     return _lib
 
 
@@ -312,6 +317,34 @@ class Frontend(_Instance):
         st = np.zeros(32, np.int32)
         _ck(self.ctx.lib.msdr_frontend_get_state(self.h, C.c_uint32(channel), _hp(st)))
         return st
+
+
+class Syncam(_Instance):
+    """The PLL branch of the demod switch (Minimal-SDR.ino:631-688), batched over channels."""
+    _destroy = "msdr_syncam_destroy"
+
+    def __init__(self, ctx, channels):
+        self.ctx = ctx
+        h = _p()
+        _ck(ctx.lib.msdr_syncam_create(ctx.h, C.c_uint32(channels), C.byref(h)))
+        self.h = h
+
+    def process(self, d_i, d_q, d_out, n, d_mode=None):
+        _ck(self.ctx.lib.msdr_syncam_q15(self.h, d_mode.ptr if d_mode is not None else None, d_i.ptr, d_q.ptr, d_out.ptr, C.c_uint32(n)))
+
+    def reset(self):
+        _ck(self.ctx.lib.msdr_syncam_reset(self.h))
+
+    def state(self, channel=0):
+        st = np.zeros(3, np.float32)
+        _ck(self.ctx.lib.msdr_syncam_get_state(self.h, C.c_uint32(channel), _hp(st)))
+        return st
+
+
+def syncam_constants():
+    c = np.zeros(4, np.float32)
+    load_library().msdr_syncam_constants(_hp(c))
+    return c
 
 
 def amp_multiplier(n):

@@ -719,3 +719,49 @@ void orc_frontend_run(orc_frontend *f, const uint16_t *adc, int16_t *out, uint32
         orc_agc_block(&f->agc, o);
     }
 }
+
+/* ======================================================================================
+ * Row f2: SYNCAM PLL, Minimal-SDR.ino:631-688.  See msdr_oracle.h.
+ * ====================================================================================== */
+#define ORC_PI_ARDUINO 3.1415926535897932384626433832795   /* Arduino.h's PI (a double literal) */
+#define ORC_SAMPLE_RATE 24000                              /* Minimal-SDR.ino:85 */
+
+void orc_syncam_init(orc_syncam *s) { s->fil_out = 0.0f; s->omega2 = 0.0f; s->phzerror = 0.0f; }
+
+void orc_syncam_constants(float c[4])
+{
+    static const float omegaN = 400.0;                                                     /* :637 */
+    static const float zeta = 0.45;                                                        /* :638 */
+    const float omega_min = 2.0 * ORC_PI_ARDUINO * -4000.0 / ORC_SAMPLE_RATE;              /* :639 */
+    const float omega_max = 2.0 * ORC_PI_ARDUINO * 4000.0 / ORC_SAMPLE_RATE;               /* :640 */
+    const float g1 = 1.0 - exp(-2.0 * omegaN * zeta / ORC_SAMPLE_RATE);                    /* :641 */
+    const float g2 = -g1 + 2.0 * (1 - exp(-omegaN * zeta / ORC_SAMPLE_RATE) * cosf(omegaN / ORC_SAMPLE_RATE * sqrtf(1.0 - zeta * zeta)));   /* :642 */
+    c[0] = omega_min; c[1] = omega_max; c[2] = g1; c[3] = g2;
+}
+
+void orc_syncam_q15(orc_syncam *s, const int16_t *I, const int16_t *Q, int16_t *out, uint32_t n)
+{
+    float c[4];
+    orc_syncam_constants(c);
+    const float omega_min = c[0], omega_max = c[1], g1 = c[2], g2 = c[3];
+    float fil_out = s->fil_out, omega2 = s->omega2, phzerror = s->phzerror;
+    for (uint32_t i = 0; i < n; i++) {
+        const float Sin = (float)sin((double)phzerror);                 /* sinf, correctly rounded   :660 */
+        const float Cos = (float)cos((double)phzerror);                 /* cosf                      :661 */
+        const float ai = Cos * (float)I[i], bi = Sin * (float)I[i];     /* :662-663 */
+        const float aq = Cos * (float)Q[i], bq = Sin * (float)Q[i];     /* :664-665 */
+        const float corr0 = +ai + bq;                                   /* :667 */
+        const float corr1 = -bi + aq;                                   /* :668 */
+        out[i] = (int16_t)(uint16_t)(uint32_t)(int32_t)corr0;           /* :670 */
+        const float det = (float)atan2((double)corr1, (double)corr0);   /* atan2f                    :674 */
+        const float del_out = fil_out;                                  /* :677 */
+        omega2 = omega2 + g2 * det;                                     /* :678 */
+        if (omega2 < omega_min) omega2 = omega_min;                     /* :679 */
+        else if (omega2 > omega_max) omega2 = omega_max;                /* :680 */
+        fil_out = g1 * det + omega2;                                    /* :681 */
+        phzerror = phzerror + del_out;                                  /* :682 */
+        while ((double)phzerror >= 2 * ORC_PI_ARDUINO) phzerror = (float)((double)phzerror - 2.0 * ORC_PI_ARDUINO);   /* :685 */
+        while ((double)phzerror < 0.0) phzerror = (float)((double)phzerror + 2.0 * ORC_PI_ARDUINO);                  /* :686 */
+    }
+    s->fil_out = fil_out; s->omega2 = omega2; s->phzerror = phzerror;
+}

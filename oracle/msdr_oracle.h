@@ -194,6 +194,19 @@ void orc_frontend_init(orc_frontend *f, uint16_t first_conversion);
  * block k applies from block k+1 on (the reference has the record queue in between; one block is the shortest delay). */
 void orc_frontend_run(orc_frontend *f, const uint16_t *adc, int16_t *out, uint32_t n_blocks);
 
+/* ======================================================================================
+ * Row f2: synchronous AM, the PLL branch of the demod switch on Teensy 3.5/3.6
+ * (Minimal-SDR.ino:631-688; "code adapted from the wdsp library").  Sample-recursive.
+ * UNPINNED (demodulation() cannot be built here).  Reading of the library calls: sinf / cosf /
+ * atan2f are taken as CORRECTLY ROUNDED float functions (computed in double, rounded once);
+ * newlib's on the Teensy are within 1 ulp of that.  `p_dac[i] = corr[0]` converts like the
+ * Cortex-M4 does (vcvt to int32, store halfword): truncate toward zero, keep the low 16 bits.
+ * ====================================================================================== */
+typedef struct { float fil_out, omega2, phzerror; } orc_syncam;             /* the statics at :643-645 */
+void orc_syncam_init(orc_syncam *s);
+void orc_syncam_constants(float c[4]);      /* omega_min, omega_max, g1, g2 as the initialisers at :639-642 evaluate */
+void orc_syncam_q15(orc_syncam *s, const int16_t *I, const int16_t *Q, int16_t *out, uint32_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,10 @@ class Agc(C.Structure):
                 ("multiplier", C.c_int32)]
 
 
+class Syncam(C.Structure):
+    _fields_ = [("fil_out", C.c_float), ("omega2", C.c_float), ("phzerror", C.c_float)]
+
+
 class Frontend(C.Structure):
     _fields_ = [("dc", DcBlock), ("agc", Agc)]
 
@@ -207,6 +211,23 @@ class Oracle:
         return y
 
     # ---- A9 -----------------------------------------------------------------------------
+    # ---- row f2: SYNCAM PLL ----
+    def syncam_new(self):
+        s = Syncam()
+        self.lib.orc_syncam_init(C.byref(s))
+        return s
+
+    def syncam_q15(self, s, i, q):
+        i, q = np.ascontiguousarray(i, np.int16), np.ascontiguousarray(q, np.int16)
+        out = np.empty(i.size, np.int16)
+        self.lib.orc_syncam_q15(C.byref(s), _ptr(i), _ptr(q), _ptr(out), C.c_uint32(i.size))
+        return out
+
+    def syncam_constants(self):
+        c = np.zeros(4, np.float32)
+        self.lib.orc_syncam_constants(_ptr(c))
+        return c
+
     # ---- row f1: front end (DC block, AudioAmplifier, AGC) ----
     def frontend_new(self, first_conversion=0, agc_on=True, gain=None):
         f = Frontend()

@@ -202,6 +202,22 @@ int msdr_syncam_get_state(msdr_syncam *S, uint32_t channel, float state[3]);    
 void msdr_syncam_constants(float c[4]);                                         /* omega_min, omega_max, g1, g2 (:639-642) */
 int msdr_syncam_destroy(msdr_syncam *S);
 
+/* ======================================================================================
+ * LMS automatic notch / noise reduction (Minimal-SDR.ino:702-770), the step
+ * between the demod switch and queue_dac.playBuffer().  ANR_on: 0 = off, 1 = notch filter
+ * (output = error), 2 = noise reduction (output = y).  State per channel = the statics
+ * ANR_lidx, ANR_ngamma, ANR_in_idx, ANR_w[64] and the part of ANR_d[512] that is ever read.
+ * d_anr_on: device int32 [channels] or NULL (then anr_on_all).  In place.
+ * In the fused Q15 chain: msdr_chain_set_anr().
+ * ====================================================================================== */
+typedef struct msdr_anr msdr_anr;
+#define MSDR_ANR_STATE_FLOATS 196u   /* lidx, ngamma, in_idx (int bits), pad | w[64] | d[128] (slot = ANR_in_idx & 127) */
+int msdr_anr_create(msdr_ctx *ctx, uint32_t channels, msdr_anr **out);
+int msdr_anr_q15(msdr_anr *A, const int32_t *d_anr_on, int32_t anr_on_all, q15_t *d_data, uint32_t blockSize);
+int msdr_anr_reset(msdr_anr *A);
+int msdr_anr_get_state(msdr_anr *A, uint32_t channel, float state[MSDR_ANR_STATE_FLOATS]);
+int msdr_anr_destroy(msdr_anr *A);
+
 /* Stateless per-block stages. */
 /* Minimal-SDR.ino:546-558; block must start at a sample index = 0 (mod 4), as every 128-block does */
 int msdr_mix_fs4_q15(msdr_ctx *ctx, const q15_t *d_x, q15_t *d_i, q15_t *d_q, uint32_t channels, uint32_t blockSize);
@@ -272,6 +288,10 @@ int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_chain **
 int msdr_chain_process(msdr_chain *chain, const int16_t *d_if, void *d_audio, uint64_t n_samples);
 int msdr_chain_reset(msdr_chain *chain);                     /* init_FIR(): zero FIR + IIR state, phase 0 */
 int msdr_chain_set_mode(msdr_chain *chain, uint32_t channel, int32_t mode, int32_t tapset);
+/* Q15 chains: ANR_on per channel (host array of `channels` values, or NULL: anr_on_all for every channel); the LMS filter
+ * then runs between the demodulator and the biquad nodes (Minimal-SDR.ino:702-770).  Its state is created on first use and
+ * cleared by msdr_chain_reset(). */
+int msdr_chain_set_anr(msdr_chain *chain, const int32_t *anr_on, int32_t anr_on_all);
 int msdr_chain_destroy(msdr_chain *chain);
 /* introspection for benchmarks/tests: name of the main kernel variant and launch geometry of the last call */
 typedef struct {

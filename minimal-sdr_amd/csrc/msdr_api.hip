@@ -783,6 +783,73 @@ extern "C" int msdr_syncam_destroy(msdr_syncam *S)
 }
 
 // ------------------------------------------------------------------------------------------------
+// LMS automatic notch / noise reduction
+// ------------------------------------------------------------------------------------------------
+struct msdr_anr {
+    msdr_ctx *ctx;
+    uint32_t channels;
+    float *d_state;        // [channels][kAnrStateFloats]
+};
+static int anr_init_state(msdr_anr *A)
+{
+    std::vector<float> h((size_t)A->channels * kAnrStateFloats, 0.0f);
+    for (uint32_t ch = 0; ch < A->channels; ch++) { h[(size_t)ch * kAnrStateFloats] = 120.0f; h[(size_t)ch * kAnrStateFloats + 1] = 0.001f; }   // .ino:715,:718
+    HIP_TRY(hipMemcpyAsync(A->d_state, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, A->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(A->ctx->stream));
+    return 0;
+}
+extern "C" int msdr_anr_create(msdr_ctx *ctx, uint32_t channels, msdr_anr **out)
+{
+    if (!out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "out is null");
+    *out = nullptr;
+    if (int rc = bind(ctx)) return rc;
+    if (channels == 0) return fail(MSDR_STATUS_ARGUMENT_ERROR, "channels == 0");
+    static_assert(kAnrStateFloats == MSDR_ANR_STATE_FLOATS, "state record size");
+    msdr_anr *A = new (std::nothrow) msdr_anr();
+    if (!A) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
+    A->ctx = ctx; A->channels = channels; A->d_state = nullptr;
+    if (int rc = dzalloc(ctx, (size_t)channels * kAnrStateFloats, &A->d_state)) { delete A; return rc; }
+    if (int rc = anr_init_state(A)) { hipFree(A->d_state); delete A; return rc; }
+    *out = A;
+    return 0;
+}
+extern "C" int msdr_anr_q15(msdr_anr *A, const int32_t *d_anr_on, int32_t anr_on_all, q15_t *d_data, uint32_t blockSize)
+{
+    if (!A) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
+    if (int rc = bind(A->ctx)) return rc;
+    if (blockSize == 0) return 0;
+    if (!d_data) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    if (!d_anr_on && anr_on_all <= 0) return 0;                       // .ino:702
+    hipLaunchKernelGGL(anr_kernel, dim3((A->channels + 63) / 64), dim3(64), 0, A->ctx->stream, (short *)d_data, A->d_state,
+                       (const int *)d_anr_on, (int)anr_on_all, (int)A->channels, (long long)blockSize);
+    return launch_check("anr_kernel");
+}
+extern "C" int msdr_anr_reset(msdr_anr *A)
+{
+    if (!A) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
+    if (int rc = bind(A->ctx)) return rc;
+    return anr_init_state(A);
+}
+extern "C" int msdr_anr_get_state(msdr_anr *A, uint32_t channel, float state[MSDR_ANR_STATE_FLOATS])
+{
+    if (!A || !state) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    if (int rc = bind(A->ctx)) return rc;
+    if (channel >= A->channels) return fail(MSDR_STATUS_ARGUMENT_ERROR, "channel out of range");
+    HIP_TRY(hipStreamSynchronize(A->ctx->stream));
+    HIP_TRY(hipMemcpy(state, A->d_state + (size_t)channel * kAnrStateFloats, kAnrStateFloats * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int msdr_anr_destroy(msdr_anr *A)
+{
+    if (!A) return 0;
+    if (int rc = bind(A->ctx)) return rc;
+    (void)hipStreamSynchronize(A->ctx->stream);
+    hipFree(A->d_state);
+    delete A;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused chain
 // ------------------------------------------------------------------------------------------------
 struct msdr_chain {
@@ -840,6 +907,9 @@ struct msdr_chain {
     msdr_syncam *pll;                 // Q15 + MSDR_CHAIN_SYNCAM_PLL: the PLL demodulator of SYNCAM channels and its Q scratch
     int16_t *d_pll_q;
     size_t pll_q_cap;
+    msdr_anr *anr;                    // Q15: LMS notch / noise reduction between demodulator and biquad nodes (msdr_chain_set_anr)
+    int *d_anr_on;
+    int anr_all;
     msdr_chain_info info;
     // optional per-launch timing of the main kernel
     bool timing;
@@ -859,6 +929,8 @@ static void chain_free(msdr_chain *c)
     for (int k = 0; k < 2; k++) if (c->nodes[k]) msdr_biquad_q15_destroy(c->nodes[k]);
     if (c->pll) msdr_syncam_destroy(c->pll);
     hipFree(c->d_pll_q);
+    if (c->anr) msdr_anr_destroy(c->anr);
+    hipFree(c->d_anr_on);
     for (auto &e : c->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete c;
 }
@@ -914,6 +986,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->flags = cfg->flags; c->mfw_nw = 0; c->mfw_waves_per_cu = 0; c->d_bq_state_alt = nullptr; c->d_units = nullptr; c->units_cap = 0;
     c->mode_gen = 1; c->units_mode_gen = 0; c->units_nseg = 0; c->units_wgs = 0;
     c->pll = nullptr; c->d_pll_q = nullptr; c->pll_q_cap = 0;
+    c->anr = nullptr; c->d_anr_on = nullptr; c->anr_all = 0;
     if (f32) {
         c->h_coef_i.resize(c->tapsets); c->h_coef_q.resize(c->tapsets);
         for (uint32_t s = 0; s < c->tapsets; s++) {
@@ -1432,6 +1505,9 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     if (pll_active)            // SYNCAM channels: I (in d_audio) and Q (scratch) -> PLL demodulator -> audio, before the biquad nodes
         if (int rc = msdr_syncam_q15(c->pll, c->d_mode, (const q15_t *)d_audio, c->d_pll_q, (q15_t *)d_audio, (uint32_t)n_samples)) return rc;
 
+    if (c->anr && (c->d_anr_on || c->anr_all > 0))      // LMS notch / noise reduction (.ino:702-770), then the biquad nodes
+        if (int rc = msdr_anr_q15(c->anr, c->d_anr_on, c->anr_all, (q15_t *)d_audio, (uint32_t)n_samples)) return rc;
+
     if (c->nnodes == 2) {      // biquad1_dac -> biquad2_dac in one pass over the audio
         hipLaunchKernelGGL((biquad_teensy_kernel<2>), dim3((c->channels + 63) / 64), dim3(64), 0, c->ctx->stream, (short *)d_audio,
                            c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);
@@ -1466,6 +1542,7 @@ extern "C" int msdr_chain_reset(msdr_chain *c)
     if (c->d_bq_state) HIP_TRY(hipMemsetAsync(c->d_bq_state, 0, (size_t)c->channels * kBqStateFloats * sizeof(float), c->ctx->stream));
     // the reference never clears biquad history on retune (filter_biquad.cpp:95-97); init_FIR() only zeroes the FIR state.
     if (c->pll) if (int rc = msdr_syncam_reset(c->pll)) return rc;
+    if (c->anr) if (int rc = msdr_anr_reset(c->anr)) return rc;
     c->phase = 0; c->gen++;
     return 0;
 }
@@ -1533,6 +1610,22 @@ extern "C" int msdr_chain_set_mode(msdr_chain *c, uint32_t channel, int32_t mode
     HIP_TRY(hipMemcpyAsync(c->d_mode + channel, &mode, sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));
     HIP_TRY(hipMemcpyAsync(c->d_tapset + channel, &tapset, sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));
     HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    return 0;
+}
+
+extern "C" int msdr_chain_set_anr(msdr_chain *c, const int32_t *anr_on, int32_t anr_on_all)
+{
+    if (!c) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null chain");
+    if (int rc = bind(c->ctx)) return rc;
+    if (c->arith != MSDR_ARITH_Q15) return fail(MSDR_STATUS_ARGUMENT_ERROR, "the LMS filter works on the int16 audio of a Q15 chain");
+    if (!c->anr) if (int rc = msdr_anr_create(c->ctx, c->channels, &c->anr)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    hipFree(c->d_anr_on); c->d_anr_on = nullptr;
+    c->anr_all = anr_on_all;
+    if (anr_on) {
+        std::vector<int> h(anr_on, anr_on + c->channels);
+        if (int rc = upload(c->ctx, h, &c->d_anr_on)) return rc;
+    }
     return 0;
 }
 

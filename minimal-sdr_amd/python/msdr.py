@@ -85,6 +85,9 @@ def load_library(path=None):
         _lib.msdr_frontend_prime.argtypes = [_p, _p, C.c_uint32]
         _lib.msdr_frontend_get_state.argtypes = [_p, C.c_uint32, _p]
         _lib.msdr_amp_q15.argtypes = [_p, C.c_int32, _p, C.c_uint32, C.c_uint32, _p]
+        _lib.msdr_anr_q15.argtypes = [_p, _p, C.c_int32, _p, C.c_uint32]
+        _lib.msdr_anr_get_state.argtypes = [_p, C.c_uint32, _p]
+        _lib.msdr_chain_set_anr.argtypes = [_p, _p, C.c_int32]
         _lib.msdr_syncam_q15.argtypes = [_p, _p, _p, _p, _p, C.c_uint32]
         _lib.msdr_syncam_get_state.argtypes = [_p, C.c_uint32, _p]
         _lib.msdr_syncam_constants.argtypes = [_p]
@@ -341,6 +344,28 @@ class Syncam(_Instance):
         return st
 
 
+class Anr(_Instance):
+    """LMS automatic notch / noise reduction (Minimal-SDR.ino:702-770), batched over channels."""
+    _destroy = "msdr_anr_destroy"
+
+    def __init__(self, ctx, channels):
+        self.ctx = ctx
+        h = _p()
+        _ck(ctx.lib.msdr_anr_create(ctx.h, C.c_uint32(channels), C.byref(h)))
+        self.h = h
+
+    def process(self, d_data, n, anr_on=1, d_anr_on=None):
+        _ck(self.ctx.lib.msdr_anr_q15(self.h, d_anr_on.ptr if d_anr_on is not None else None, C.c_int32(anr_on), d_data.ptr, C.c_uint32(n)))
+
+    def reset(self):
+        _ck(self.ctx.lib.msdr_anr_reset(self.h))
+
+    def state(self, channel=0):
+        st = np.zeros(196, np.float32)
+        _ck(self.ctx.lib.msdr_anr_get_state(self.h, C.c_uint32(channel), _hp(st)))
+        return st
+
+
 def syncam_constants():
     c = np.zeros(4, np.float32)
     load_library().msdr_syncam_constants(_hp(c))
@@ -419,6 +444,10 @@ class Chain(_Instance):
 
     def set_mode(self, channel, mode, tapset=0):
         _ck(self.ctx.lib.msdr_chain_set_mode(self.h, C.c_uint32(channel), C.c_int32(mode), C.c_int32(tapset)))
+
+    def set_anr(self, anr_on=None, anr_on_all=0):
+        a = np.ascontiguousarray(anr_on, np.int32) if anr_on is not None else None
+        _ck(self.ctx.lib.msdr_chain_set_anr(self.h, _hp(a), C.c_int32(anr_on_all)))
 
     def info(self):
         i = ChainInfo()

@@ -765,3 +765,57 @@ void orc_syncam_q15(orc_syncam *s, const int16_t *I, const int16_t *Q, int16_t *
     }
     s->fil_out = fil_out; s->omega2 = omega2; s->phzerror = phzerror;
 }
+
+/* ======================================================================================
+ * Row f3: LMS automatic notch / noise reduction, Minimal-SDR.ino:702-770.  See msdr_oracle.h.
+ * ====================================================================================== */
+void orc_anr_init(orc_anr *a)
+{
+    memset(a, 0, sizeof *a);
+    a->lidx = 120.0f;          /* :715 */
+    a->ngamma = 0.001f;        /* :718 */
+    a->in_idx = 0;             /* :723 */
+}
+
+void orc_anr_q15(orc_anr *a, int ANR_on, int16_t *p_dac, uint32_t n)
+{
+    if (!(ANR_on > 0)) return;                                    /* :702 */
+    static const int ANR_taps = ORC_ANR_TAPS, ANR_delay = ORC_ANR_DELAY;
+    static const float ANR_two_mu = 0.001, ANR_gamma = 0.1;
+    static const float ANR_lidx_min = 0.0, ANR_lidx_max = 200.0;
+    static const float ANR_den_mult = 6.25e-10, ANR_lincr = 1.0, ANR_ldecr = 3.0;
+    const int ANR_mask = ORC_ANR_DLINE - 1;
+    float ANR_lidx = a->lidx, ANR_ngamma = a->ngamma;
+    int ANR_in_idx = a->in_idx;
+    float *ANR_d = a->d, *ANR_w = a->w;
+    for (uint32_t i = 0; i < n; i++) {
+        int j, idx;
+        float c0, c1, y, error, sigma, inv_sigp, nel, nev;
+        ANR_d[ANR_in_idx] = p_dac[i];                             /* :734 */
+        y = 0; sigma = 0;
+        for (j = 0; j < ANR_taps; j++) {                          /* :739-744 */
+            idx = (ANR_in_idx + j + ANR_delay) & ANR_mask;
+            y += ANR_w[j] * ANR_d[idx];
+            sigma += ANR_d[idx] * ANR_d[idx];
+        }
+        inv_sigp = 1.0 / (sigma + 1e-10);                         /* :745 */
+        error = ANR_d[ANR_in_idx] - y;                            /* :746 */
+        if (ANR_on == 1) p_dac[i] = (int16_t)(uint16_t)(uint32_t)(int32_t)error;     /* :749 notch filter */
+        else p_dac[i] = (int16_t)(uint16_t)(uint32_t)(int32_t)y;                     /* :750 noise reduction */
+        if ((nel = error * (1.0 - ANR_two_mu * sigma * inv_sigp)) < 0.0) nel = -nel;                                           /* :752 */
+        if ((nev = ANR_d[ANR_in_idx] - (1.0 - ANR_two_mu * ANR_ngamma) * y - ANR_two_mu * error * sigma * inv_sigp) < 0.0) nev = -nev;   /* :753 */
+        if (nev < nel) {                                          /* :754-757, as written */
+            if ((ANR_lidx += ANR_lincr) > ANR_lidx_max) ANR_lidx = ANR_lidx_max;
+            else if ((ANR_lidx -= ANR_ldecr) < ANR_lidx_min) ANR_lidx = ANR_lidx_min;
+        }
+        ANR_ngamma = ANR_gamma * (ANR_lidx * ANR_lidx) * (ANR_lidx * ANR_lidx) * ANR_den_mult;   /* :758 */
+        c0 = 1.0 - ANR_two_mu * ANR_ngamma;                       /* :760 */
+        c1 = ANR_two_mu * error * inv_sigp;                       /* :761 */
+        for (j = 0; j < ANR_taps; j++) {                          /* :763-767 */
+            idx = (ANR_in_idx + j + ANR_delay) & ANR_mask;
+            ANR_w[j] = c0 * ANR_w[j] + c1 * ANR_d[idx];
+        }
+        ANR_in_idx = (ANR_in_idx + ANR_mask) & ANR_mask;          /* :768 */
+    }
+    a->lidx = ANR_lidx; a->ngamma = ANR_ngamma; a->in_idx = ANR_in_idx;
+}

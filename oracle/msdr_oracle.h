@@ -207,6 +207,27 @@ void orc_syncam_init(orc_syncam *s);
 void orc_syncam_constants(float c[4]);      /* omega_min, omega_max, g1, g2 as the initialisers at :639-642 evaluate */
 void orc_syncam_q15(orc_syncam *s, const int16_t *I, const int16_t *Q, int16_t *out, uint32_t n);
 
+/* ======================================================================================
+ * Row f3: LMS automatic notch / noise reduction between the demod switch and
+ * queue_dac.playBuffer() (Minimal-SDR.ino:702-770, "variable leak LMS ... Warren Pratt's wdsp").
+ * Sample-recursive, 64 taps, delay 16, 512-entry delay line.  UNPINNED (inside demodulation()).
+ * Arithmetic as the source states it under C's conversions: float variables, double where an
+ * unsuffixed literal (1.0, 1e-10, 0.0) enters the expression; the two 64-term sums run j = 0..63
+ * in order; `p_dac[i] = error` converts like `p_dac[i] = corr[0]` in row f2.
+ * ====================================================================================== */
+#define ORC_ANR_DLINE 512
+#define ORC_ANR_TAPS 64
+#define ORC_ANR_DELAY 16
+typedef struct {
+    float lidx, ngamma;            /* ANR_lidx = 120, ANR_ngamma = 0.001 (:715, :718) */
+    int32_t in_idx;                /* ANR_in_idx (:723) */
+    float d[ORC_ANR_DLINE];        /* ANR_d (:724) */
+    float w[ORC_ANR_DLINE];        /* ANR_w (:725; only the first 64 are used) */
+} orc_anr;
+void orc_anr_init(orc_anr *a);
+/* anr_on: 1 = notch filter (output = error), 2 = noise reduction (output = y); 0 = off (data untouched, state untouched) */
+void orc_anr_q15(orc_anr *a, int anr_on, int16_t *data, uint32_t n);
+
 #ifdef __cplusplus
 }
 #endif

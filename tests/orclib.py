@@ -81,6 +81,10 @@ class Syncam(C.Structure):
     _fields_ = [("fil_out", C.c_float), ("omega2", C.c_float), ("phzerror", C.c_float)]
 
 
+class Anr(C.Structure):
+    _fields_ = [("lidx", C.c_float), ("ngamma", C.c_float), ("in_idx", C.c_int32), ("d", C.c_float * 512), ("w", C.c_float * 512)]
+
+
 class Frontend(C.Structure):
     _fields_ = [("dc", DcBlock), ("agc", Agc)]
 
@@ -211,6 +215,17 @@ class Oracle:
         return y
 
     # ---- A9 -----------------------------------------------------------------------------
+    # ---- row f3: LMS automatic notch / noise reduction ----
+    def anr_new(self):
+        a = Anr()
+        self.lib.orc_anr_init(C.byref(a))
+        return a
+
+    def anr_q15(self, a, anr_on, data):
+        d = np.array(data, np.int16)
+        self.lib.orc_anr_q15(C.byref(a), C.c_int(int(anr_on)), _ptr(d), C.c_uint32(d.size))
+        return d
+
     # ---- row f2: SYNCAM PLL ----
     def syncam_new(self):
         s = Syncam()

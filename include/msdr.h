@@ -219,6 +219,9 @@ int msdr_anr_get_state(msdr_anr *A, uint32_t channel, float state[MSDR_ANR_STATE
 int msdr_anr_destroy(msdr_anr *A);
 
 /* Stateless per-block stages. */
+/* what AudioOutputAnalog::isr writes to the 12-bit DAC, output_dac.cpp:139-151: (sample + 32768) >> 4;
+ * d_src == NULL = no block arrived: 2048 (mid-scale).  d_dest may alias d_src. */
+int msdr_dac_format_q15(msdr_ctx *ctx, const q15_t *d_src, q15_t *d_dest, uint32_t channels, uint32_t blockSize);
 /* Minimal-SDR.ino:546-558; block must start at a sample index = 0 (mod 4), as every 128-block does */
 int msdr_mix_fs4_q15(msdr_ctx *ctx, const q15_t *d_x, q15_t *d_i, q15_t *d_q, uint32_t channels, uint32_t blockSize);
 /* AudioEffectFreqConv::update, freq_conv.cpp:30-116, in place on d_i/d_q.  osc_i/osc_q: host tables of

@@ -67,6 +67,7 @@ static int bind(msdr_ctx *ctx)
 {
     if (!ctx) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
+    (void)hipGetLastError();      // launch_check() reads the sticky last error: start every entry point with a clean slate
     return 0;
 }
 
@@ -847,6 +848,16 @@ extern "C" int msdr_anr_destroy(msdr_anr *A)
     hipFree(A->d_state);
     delete A;
     return 0;
+}
+
+extern "C" int msdr_dac_format_q15(msdr_ctx *ctx, const q15_t *d_src, q15_t *d_dest, uint32_t channels, uint32_t blockSize)
+{
+    if (int rc = bind(ctx)) return rc;
+    const long long total = (long long)channels * blockSize;
+    if (total == 0) return 0;
+    if (!d_dest) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    hipLaunchKernelGGL(dac_format_kernel, dim3(grid_1d((total + 7) / 8)), dim3(256), 0, ctx->stream, (const short *)d_src, (short *)d_dest, total);
+    return launch_check("dac_format_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -88,6 +88,7 @@ def load_library(path=None):
         _lib.msdr_anr_q15.argtypes = [_p, _p, C.c_int32, _p, C.c_uint32]
         _lib.msdr_anr_get_state.argtypes = [_p, C.c_uint32, _p]
         _lib.msdr_chain_set_anr.argtypes = [_p, _p, C.c_int32]
+        _lib.msdr_dac_format_q15.argtypes = [_p, _p, _p, C.c_uint32, C.c_uint32]
         _lib.msdr_syncam_q15.argtypes = [_p, _p, _p, _p, _p, C.c_uint32]
         _lib.msdr_syncam_get_state.argtypes = [_p, C.c_uint32, _p]
         _lib.msdr_syncam_constants.argtypes = [_p]
@@ -364,6 +365,10 @@ class Anr(_Instance):
         st = np.zeros(196, np.float32)
         _ck(self.ctx.lib.msdr_anr_get_state(self.h, C.c_uint32(channel), _hp(st)))
         return st
+
+
+def dac_format_q15(ctx, d_src, d_dest, channels, n):
+    _ck(ctx.lib.msdr_dac_format_q15(ctx.h, d_src.ptr if d_src is not None else None, d_dest.ptr, C.c_uint32(channels), C.c_uint32(n)))
 
 
 def syncam_constants():

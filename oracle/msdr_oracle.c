@@ -819,3 +819,9 @@ void orc_anr_q15(orc_anr *a, int ANR_on, int16_t *p_dac, uint32_t n)
     }
     a->lidx = ANR_lidx; a->ngamma = ANR_ngamma; a->in_idx = ANR_in_idx;
 }
+
+/* Row f4: output_dac.cpp:139-151 */
+void orc_dac_format(const int16_t *src, int16_t *dest, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++) dest[i] = src ? (int16_t)(((int32_t)src[i] + 32768) >> 4) : (int16_t)2048;
+}

@@ -228,6 +228,10 @@ void orc_anr_init(orc_anr *a);
 /* anr_on: 1 = notch filter (output = error), 2 = noise reduction (output = y); 0 = off (data untouched, state untouched) */
 void orc_anr_q15(orc_anr *a, int anr_on, int16_t *data, uint32_t n);
 
+/* ---- Row f4 (first half): what AudioOutputAnalog::isr hands the 12-bit DAC, src/Audio/output_dac.cpp:139-151:
+ * ((sample) + 32768) >> 4 per sample; 2048 (mid-scale) when no block arrived.  UNPINNED (needs the Teensyduino core). */
+void orc_dac_format(const int16_t *src /* NULL = no block */, int16_t *dest, uint32_t n);
+
 #ifdef __cplusplus
 }
 #endif

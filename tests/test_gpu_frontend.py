@@ -111,3 +111,20 @@ def test_amp_q15_stage(ctx, orc):
             assert not sent
         else:
             assert sent and np.array_equal(d.download().reshape(-1), want), gain
+
+
+def test_dac_format_stage(ctx, orc):
+    """output_dac.cpp:139-151: (sample + 32768) >> 4, mid-scale when no block arrived; odd sizes take the scalar tail."""
+    rng = np.random.default_rng(9)
+    for ch, n in ((3, 128), (5, 131), (1, 7)):
+        x = rng.integers(-32768, 32768, (ch, n)).astype(np.int16)
+        x.flat[:4] = [-32768, 32767, 0, -1]
+        d, o = ctx.to_device(x), ctx.array((ch, n), np.int16)
+        msdr.dac_format_q15(ctx, d, o, ch, n)
+        want = ((x.astype(np.int32) + 32768) >> 4).astype(np.int16)
+        assert np.array_equal(o.download(), want)
+        ref = np.empty(x.size, np.int16)
+        orc.lib.orc_dac_format(x.ctypes.data_as(orclib.C.c_void_p), ref.ctypes.data_as(orclib.C.c_void_p), orclib.C.c_uint32(x.size))
+        assert np.array_equal(ref.reshape(x.shape), want)
+        msdr.dac_format_q15(ctx, None, o, ch, n)
+        assert (o.download() == 2048).all()

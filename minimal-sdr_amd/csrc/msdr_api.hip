@@ -903,6 +903,7 @@ struct msdr_chain {
     uint32_t flags;
     int mfw_nw, mfw_waves_per_cu;
     float *d_bq_state_alt;
+    float *d_mw_iir;                  // folded-IIR constants (MwIirConsts) or null
     int *d_units;
     size_t units_cap;
     uint64_t mode_gen, units_mode_gen;
@@ -936,7 +937,7 @@ static void chain_free(msdr_chain *c)
     hipFree(c->d_hist[0]); hipFree(c->d_hist[1]); hipFree(c->d_bq); hipFree(c->d_bq_state);
     hipFree(c->d_ftaps); hipFree(c->d_fset); hipFree(c->d_bq_fold);
     hipFree(c->d_fft_h); hipFree(c->d_fft_tw); hipFree(c->d_bq_fft); hipFree(c->d_mf_tab); hipFree(c->d_bq_mf); hipFree(c->d_bq_mf32);
-    hipFree(c->d_bq_state_alt); hipFree(c->d_units);
+    hipFree(c->d_bq_state_alt); hipFree(c->d_units); hipFree(c->d_mw_iir);
     for (int k = 0; k < 2; k++) if (c->nodes[k]) msdr_biquad_q15_destroy(c->nodes[k]);
     if (c->pll) msdr_syncam_destroy(c->pll);
     hipFree(c->d_pll_q);
@@ -994,7 +995,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->pole_radius = c->nstages ? max_pole_radius(cfg->biquad_coeffs, (int)c->nstages) : 0.0;
     c->cur = 0; c->phase = 0; c->timing = false; c->timed_ms = 0; c->timed_launches = 0;
     c->gen = 1; c->dh_cache.resize(c->channels); c->dh_gen.assign(c->channels, 0);
-    c->flags = cfg->flags; c->mfw_nw = 0; c->mfw_waves_per_cu = 0; c->d_bq_state_alt = nullptr; c->d_units = nullptr; c->units_cap = 0;
+    c->flags = cfg->flags; c->mfw_nw = 0; c->mfw_waves_per_cu = 0; c->d_bq_state_alt = nullptr; c->d_mw_iir = nullptr; c->d_units = nullptr; c->units_cap = 0;
     c->mode_gen = 1; c->units_mode_gen = 0; c->units_nseg = 0; c->units_wgs = 0;
     c->pll = nullptr; c->d_pll_q = nullptr; c->pll_q_cap = 0;
     c->anr = nullptr; c->d_anr_on = nullptr; c->anr_all = 0;
@@ -1153,6 +1154,91 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         std::vector<double> M[2];
         M[0].resize((size_t)KI * 32); M[1].resize((size_t)KI * 32);
         std::vector<double> di(NF), dq(NF), fi(NF), fq(NF);
+        // ---- folded IIR (wave-stream kernel, SSB tables, 1 or 2 sections): the all-pole cascade's zero-state response inside a
+        // 32-sample row is a lower-triangular Toeplitz matrix L (impulse response g); B' = B L^T puts it into the FIR's own matrix
+        // product.  What is left per row is the response R sigma to the state sigma at the row's start (cascade basis:
+        // (w_s[-1], w_s[-2]) per section) and the row-to-row recurrence sigma' = z + M sigma; see MwIirConsts.
+        const int S_ = (int)c->nstages, NS = 2 * S_;
+        bool iirfold = (S_ == 1 || S_ == 2) && !(cfg->flags & MSDR_CHAIN_MFMA_WG);
+        double gap[32] = {0}, sec_a1[2] = {0, 0}, sec_a2[2] = {0, 0}, gl1[2] = {0, 0}, Rmax = 0.0;
+        std::vector<float> iirc;
+        auto run_cascade = [&](double *sig, const double *vin, double *yout, int len) {      // all-pole sections in series, state in/out
+            for (int t = 0; t < len; t++) {
+                double u = vin ? vin[t] : 0.0;
+                for (int q = 0; q < S_; q++) {
+                    const double w = u + sec_a1[q] * sig[2 * q] + sec_a2[q] * sig[2 * q + 1];
+                    sig[2 * q + 1] = sig[2 * q]; sig[2 * q] = w; u = w;
+                }
+                if (yout) yout[t] = u;
+            }
+        };
+        if (iirfold) {
+            for (int q = 0; q < S_; q++) { sec_a1[q] = cfg->biquad_coeffs[5 * q + 3]; sec_a2[q] = cfg->biquad_coeffs[5 * q + 4]; }
+            {   // impulse response (32 samples for L) and L1 norms of the partial cascades (state bounds)
+                std::vector<double> imp(8192, 0.0), y(8192);
+                imp[0] = 1.0;
+                double sg[4] = {0, 0, 0, 0};
+                run_cascade(sg, imp.data(), y.data(), 8192);
+                for (int n = 0; n < 32; n++) gap[n] = y[n];
+                if (std::fabs(y[8191]) + std::fabs(y[8190]) > 1e-12) iirfold = false;          // does not decay: no bound, keep the VALU scan
+                for (int q = 0; q < S_ && iirfold; q++) {
+                    double s2[4] = {0, 0, 0, 0}, acc = 0.0;
+                    const int keep = S_;
+                    (void)keep;
+                    // partial cascade 0..q: rerun with only q+1 sections
+                    for (int t = 0; t < 8192; t++) {
+                        double u = imp[t];
+                        for (int r = 0; r <= q; r++) { const double w = u + sec_a1[r] * s2[2 * r] + sec_a2[r] * s2[2 * r + 1]; s2[2 * r + 1] = s2[2 * r]; s2[2 * r] = w; u = w; }
+                        acc += std::fabs(u);
+                    }
+                    gl1[q] = acc;
+                }
+            }
+        }
+        if (iirfold) {
+            iirc.assign(kMwIirFloats, 0.0f);
+            double Mt[4][4] = {{0}}, Rr[32][4] = {{0}};
+            for (int j = 0; j < NS; j++) {                          // unit state e_j, zero input, one row
+                double sg[4] = {0, 0, 0, 0}, y[32];
+                sg[j] = 1.0;
+                run_cascade(sg, nullptr, y, 32);
+                for (int m = 0; m < 32; m++) { Rr[m][j] = y[m]; Rmax = std::max(Rmax, std::fabs(y[m])); }
+                for (int i = 0; i < NS; i++) Mt[i][j] = sg[i];
+            }
+            auto matmul = [&](const double A[4][4], const double B[4][4], double C[4][4]) {
+                double t[4][4];
+                for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { t[i][j] = 0; for (int k = 0; k < 4; k++) t[i][j] += A[i][k] * B[k][j]; }
+                memcpy(C, t, sizeof t);
+            };
+            double Pw[4][4];
+            memcpy(Pw, Mt, sizeof Pw);
+            for (int k = 0; k < 4; k++) {                           // M^(2^k), stored by columns
+                for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) iirc[kMwIirPow + k * 16 + j * 4 + i] = (float)Pw[i][j];
+                matmul(Pw, Pw, Pw);
+            }
+            memcpy(Pw, Mt, sizeof Pw);
+            for (int l = 0; l < 32; l++) {                          // M^(l+1): pair-major [pair][lane] float2, pairs = the column halves the scan uses
+                const int pidx2[6] = {0, 2, 4, 6, 10, 14}, pidx1[2] = {0, 4};      // first float of each pair in the column-major 4x4
+                const int npairs = (S_ == 2) ? 6 : 2;
+                for (int q = 0; q < npairs; q++) {
+                    const int f = (S_ == 2) ? pidx2[q] : pidx1[q];
+                    for (int e = 0; e < 2; e++) iirc[kMwIirLane + (q * 32 + l) * 2 + e] = (float)Pw[(f + e) & 3][(f + e) >> 2];
+                }
+                matmul(Pw, Mt, Pw);
+            }
+            for (int m = 0; m < 32; m++) for (int k = 0; k < NS; k++) iirc[kMwIirGfix + m * 4 + k] = (m - k >= 0) ? (float)gap[m - k] : 0.0f;
+            if (Rmax * std::ldexp(1.0, kMwIirSigExp) > 60000.0) iirfold = false;
+            // response fragments for the correction MFMA: A operand, lane (m, kg), element j: kg = 1 and j < NS: R[m][j] 2^e, else 0
+            _Float16 *rh = reinterpret_cast<_Float16 *>(iirc.data() + kMwIirRfrag), *rl = rh + 512;
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const double val = ((l >> 5) == 1 && j < NS) ? Rr[l & 31][j] * std::ldexp(1.0, kMwIirSigExp) : 0.0;
+                    const _Float16 vh = (_Float16)val;
+                    rh[l * 8 + j] = vh; rl[l * 8 + j] = (_Float16)(val - (double)vh);
+                }
+            iirc[kMwIirCoef + 0] = (S_ == 2) ? (float)sec_a1[1] : 0.0f;       // the last section's feedback: w_(S-1)[n] = y[n] - a1 y[n-1] - a2 y[n-2]
+            iirc[kMwIirCoef + 1] = (S_ == 2) ? (float)sec_a2[1] : 0.0f;
+        }
         for (uint32_t s = 0; s < c->tapsets && ok; s++) {
             const float *hi = (const float *)cfg->coeffs_i[s], *hq = (const float *)cfg->coeffs_q[s];
             // taps by delay (arm_fir keeps its coefficients time-reversed: index N - 1 - delay); plain and numerator-folded
@@ -1181,12 +1267,34 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                             M[0][(size_t)i * 32 + b] = m0; M[1][(size_t)i * 32 + b] = m1;
                             maxabs = std::max(maxabs, std::max(std::fabs(m0), std::fabs(m1)));
                         }
+                    const bool fold_iir = numfold && iirfold;
+                    if (fold_iir) {                                      // B' = B L^T: columns take in the zero-state all-pole response
+                        maxabs = 0.0;
+                        for (int i = 0; i < KI; i++) {
+                            double row[32];
+                            for (int b2 = 0; b2 < 32; b2++) {
+                                double a = 0.0;
+                                for (int b = 0; b <= b2; b++) a += M[0][(size_t)i * 32 + b] * gap[b2 - b];
+                                row[b2] = a;
+                            }
+                            for (int b2 = 0; b2 < 32; b2++) { M[0][(size_t)i * 32 + b2] = row[b2]; maxabs = std::max(maxabs, std::fabs(row[b2])); }
+                        }
+                    }
                     int ex = 0;
-                    if (maxabs > 0) { std::frexp(maxabs, &ex); ex = 14 - ex; }           // maxabs * 2^ex in [2^13, 2^14)
+                    if (maxabs > 0) { std::frexp(maxabs, &ex); ex = (fold_iir ? 10 : 14) - ex; }           // maxabs * 2^ex in [2^13, 2^14) ([2^9, 2^10) with the folded IIR)
+                    if (fold_iir) {
+                        // the state sigma (in accumulator units = true / post) goes through fp16 as sigma 2^-kMwIirSigExp: keep it <= 2^15
+                        double tl1 = 0.0;
+                        for (int dl = 0; dl < nt; dl++) tl1 += std::fabs(ti[dl]) + std::fabs(tq[dl]);
+                        double smax = 0.0;
+                        for (int q = 0; q < S_; q++) smax = std::max(smax, 32768.0 * tl1 * gl1[q]);          // |w_q| in units of in_scale
+                        while (ex > -8 && smax * std::ldexp(1.0, ex - kMwIirSigExp) > 30000.0) ex--;
+                    }
                     const double scale = std::ldexp(1.0, ex);
                     Tab &T = tabs[((size_t)s * 3 + v) * P + rot];
                     memset(&T.h, 0, sizeof T.h);
                     T.h.am = (v == 2); T.h.numfold = numfold; T.h.post = (float)((double)c->in_scale / scale);
+                    T.h.iirfold = fold_iir; T.h.ipost = (float)(scale / (double)c->in_scale);
                     int ns = 0;
                     for (int o = 0; o < (v == 2 ? 2 : 1); o++)
                         for (int src = 0; src < 2; src++) {
@@ -1248,6 +1356,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                 }
                 c->mfw_waves_per_cu = best;
                 if (best > 0) rc = dzalloc(ctx, (size_t)c->channels * kBqStateFloats, &c->d_bq_state_alt);
+                if (!rc && iirfold && !iirc.empty()) rc = upload(ctx, iirc, &c->d_mw_iir);
             }
         }
     }
@@ -1457,7 +1566,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             c->units_mode_gen = c->mode_gen; c->units_nseg = nseg; c->units_wgs = (uint32_t)(units.size() / 2 / nw);
         }
         grid = c->units_wgs;
-        p.mf_units = c->d_units; p.mf_nw = nw; p.bq_state_out = c->d_bq_state_alt;
+        p.mf_units = c->d_units; p.mf_nw = nw; p.bq_state_out = c->d_bq_state_alt; p.mw_iir = c->d_mw_iir;
         { const char *e = getenv("MSDR_DBG"); p.dbg = e ? atoi(e) : 0; }
 #ifdef MSDR_STAMPS
         static unsigned long long *stamp_buf = nullptr;

@@ -443,3 +443,24 @@ def test_chain_f32_retune_mid_stream_keeps_cascade_state(ctx, orc, engine):
         want1 = orc.chain_f32(seg[1], orclib.LSB, hi, hq, sin4, cos4, bq, state=st1)
         assert rel_rms(got[0], want0) < TOL, (k, m, rel_rms(got[0], want0))
         assert rel_rms(got[1], want1) < TOL, (k, rel_rms(got[1], want1))
+
+
+def test_chain_f32_mfw_repeatable_long_stream(ctx, orc):
+    """Many short segments, a long halo (256 taps) and the folded IIR: every launch must give the same, correct stream.  (A
+    variant of the kernel that took the scan's uniform matrices through the scalar cache gave intermittently wrong rows
+    in exactly this configuration; eight fresh chains in a row catch that kind of fault.)"""
+    rng = np.random.default_rng(6)
+    n = 1 << 20
+    x = rng.integers(-8000, 8001, (1, n)).astype(np.int16)
+    hi, hq = _hilbert_pair(256)
+    oi, oq = _q15_nco(4, 1)
+    bq = _f32_biquads(orc, 2)
+    want = orc.chain_f32(x[0], orclib.LSB, hi, hq, oi, oq, bq)
+    first = None
+    for rep in range(8):
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, 1, hi, hq, mixer=msdr.MIXER_NCO, mode=orclib.LSB, osc_i=oi, osc_q=oq, biquad_coeffs=bq)
+        got = run_chain(ctx, chain, x, np.float32)[0]
+        assert rel_rms(got, want) < TOL, rep
+        if first is None:
+            first = got
+        assert np.array_equal(got, first), rep          # bit-identical from launch to launch

@@ -1159,7 +1159,8 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         // product.  What is left per row is the response R sigma to the state sigma at the row's start (cascade basis:
         // (w_s[-1], w_s[-2]) per section) and the row-to-row recurrence sigma' = z + M sigma; see MwIirConsts.
         const int S_ = (int)c->nstages, NS = 2 * S_;
-        bool iirfold = (S_ == 1 || S_ == 2) && !(cfg->flags & MSDR_CHAIN_MFMA_WG);
+        bool iirfold = (S_ == 1 || S_ == 2) && !(cfg->flags & MSDR_CHAIN_MFMA_WG) && !getenv("MSDR_NO_IIRFOLD");
+        bool amfold = false;
         double gap[32] = {0}, sec_a1[2] = {0, 0}, sec_a2[2] = {0, 0}, gl1[2] = {0, 0}, Rmax = 0.0;
         std::vector<float> iirc;
         auto run_cascade = [&](double *sig, const double *vin, double *yout, int len) {      // all-pole sections in series, state in/out
@@ -1238,6 +1239,38 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                 }
             iirc[kMwIirCoef + 0] = (S_ == 2) ? (float)sec_a1[1] : 0.0f;       // the last section's feedback: w_(S-1)[n] = y[n] - a1 y[n-1] - a2 y[n-2]
             iirc[kMwIirCoef + 1] = (S_ == 2) ? (float)sec_a2[1] : 0.0f;
+            // ---- envelope modes: the cascade cannot go into the FIR (the envelope is in between), so its zero-state response runs as
+            // its own matrix product  Y0 = L D + Rd delta:  L = full cascade (numerator * all-pole) impulse response, lower-triangular
+            // Toeplitz; delta = the previous row's last 2S inputs (numerator history), Rd their effect on this row
+            double hfull[32], Lmax = 0.0;
+            for (int m = 0; m < 32; m++) {
+                double a = 0.0;
+                for (size_t t = 0; t < cnum.size() && (int)t <= m; t++) a += cnum[t] * gap[m - (int)t];
+                hfull[m] = a; Lmax = std::max(Lmax, std::fabs(a));
+            }
+            double Rd[32][4] = {{0}};
+            for (int m = 0; m < 32; m++)
+                for (int k = 1; k <= 2 * S_; k++) {                 // input d[-k]
+                    double a = 0.0;
+                    for (int t = 0; t + k < (int)cnum.size() && t <= m; t++) a += gap[m - t] * cnum[t + k];
+                    Rd[m][4 - k] = a; Lmax = std::max(Lmax, std::fabs(a));          // element j = 4 - k: the row's inputs 28..31 in order
+                }
+            amfold = iirfold && Lmax * std::ldexp(1.0, kMwIirEnvExp) < 60000.0 && !getenv("MSDR_NO_AMFOLD");
+            _Float16 *lf = reinterpret_cast<_Float16 *>(iirc.data() + kMwIirLfrag), *df = reinterpret_cast<_Float16 *>(iirc.data() + kMwIirDfrag);
+            for (int st2 = 0; st2 < 2; st2++)
+                for (int l = 0; l < 64; l++)
+                    for (int j = 0; j < 8; j++) {
+                        const int m = l & 31, kk = (j & 3) + 8 * (2 * st2 + (j >> 2)) + 4 * (l >> 5);
+                        const double val = (m >= kk) ? hfull[m - kk] * std::ldexp(1.0, kMwIirEnvExp) : 0.0;
+                        const _Float16 vh = (_Float16)val;
+                        lf[st2 * 1024 + l * 8 + j] = vh; lf[st2 * 1024 + 512 + l * 8 + j] = (_Float16)(val - (double)vh);
+                    }
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const double val = ((l >> 5) == 1 && j < 4) ? Rd[l & 31][j] * std::ldexp(1.0, kMwIirEnvExp) : 0.0;
+                    const _Float16 vh = (_Float16)val;
+                    df[l * 8 + j] = vh; df[512 + l * 8 + j] = (_Float16)(val - (double)vh);
+                }
         }
         for (uint32_t s = 0; s < c->tapsets && ok; s++) {
             const float *hi = (const float *)cfg->coeffs_i[s], *hq = (const float *)cfg->coeffs_q[s];
@@ -1290,11 +1323,26 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                         for (int q = 0; q < S_; q++) smax = std::max(smax, 32768.0 * tl1 * gl1[q]);          // |w_q| in units of in_scale
                         while (ex > -8 && smax * std::ldexp(1.0, ex - kMwIirSigExp) > 30000.0) ex--;
                     }
+                    const bool fold_am = (v == 2) && amfold;
+                    if (fold_am) {
+                        // the envelope (accumulator units) goes through fp16 as e 2^-kMwIirEnvExp, the cascade's states as sigma 2^-kMwIirSigExp
+                        double colmax = 0.0;
+                        for (int b = 0; b < 32; b++) {
+                            double c0 = 0.0, c1 = 0.0;
+                            for (int i = 0; i < KI; i++) { c0 += std::fabs(M[0][(size_t)i * 32 + b]); c1 += std::fabs(M[1][(size_t)i * 32 + b]); }
+                            colmax = std::max(colmax, std::sqrt(c0 * c0 + c1 * c1));
+                        }
+                        const double emax = 32768.0 * colmax;                    // |envelope| / 2^ex
+                        double cl1 = 0.0, smax = 0.0;
+                        for (double cc : cnum) cl1 += std::fabs(cc);
+                        for (int q = 0; q < S_; q++) smax = std::max(smax, emax * cl1 * gl1[q]);
+                        while (ex > -8 && (emax * std::ldexp(1.0, ex - kMwIirEnvExp) > 30000.0 || smax * std::ldexp(1.0, ex - kMwIirSigExp) > 30000.0)) ex--;
+                    }
                     const double scale = std::ldexp(1.0, ex);
                     Tab &T = tabs[((size_t)s * 3 + v) * P + rot];
                     memset(&T.h, 0, sizeof T.h);
                     T.h.am = (v == 2); T.h.numfold = numfold; T.h.post = (float)((double)c->in_scale / scale);
-                    T.h.iirfold = fold_iir; T.h.ipost = (float)(scale / (double)c->in_scale);
+                    T.h.iirfold = fold_iir || fold_am; T.h.ipost = (float)(scale / (double)c->in_scale);
                     int ns = 0;
                     for (int o = 0; o < (v == 2 ? 2 : 1); o++)
                         for (int src = 0; src < 2; src++) {

@@ -904,6 +904,10 @@ struct msdr_chain {
     int mfw_nw, mfw_waves_per_cu;
     float *d_bq_state_alt;
     float *d_mw_iir;                  // folded-IIR constants (MwIirConsts) or null
+    bool mfw_ssb_fold, mfw_am_fold;   // cascade as matrix products for SSB tables / envelope tables
+    uint32_t units_wgs_ssb;           // unit table: workgroups of SSB-table units come first, envelope-table units after them
+    long long part_nseg[2], part_seg_len[2];      // the two launches choose their own time segmentation (each must fill the GPU on its own)
+    long long units_tiles;
     int *d_units;
     size_t units_cap;
     uint64_t mode_gen, units_mode_gen;
@@ -996,7 +1000,8 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->cur = 0; c->phase = 0; c->timing = false; c->timed_ms = 0; c->timed_launches = 0;
     c->gen = 1; c->dh_cache.resize(c->channels); c->dh_gen.assign(c->channels, 0);
     c->flags = cfg->flags; c->mfw_nw = 0; c->mfw_waves_per_cu = 0; c->d_bq_state_alt = nullptr; c->d_mw_iir = nullptr; c->d_units = nullptr; c->units_cap = 0;
-    c->mode_gen = 1; c->units_mode_gen = 0; c->units_nseg = 0; c->units_wgs = 0;
+    c->mode_gen = 1; c->units_mode_gen = 0; c->units_nseg = 0; c->units_wgs = 0; c->units_wgs_ssb = 0; c->mfw_ssb_fold = false; c->mfw_am_fold = false; c->units_tiles = -1;
+    c->part_nseg[0] = c->part_nseg[1] = 1; c->part_seg_len[0] = c->part_seg_len[1] = 0;
     c->pll = nullptr; c->d_pll_q = nullptr; c->pll_q_cap = 0;
     c->anr = nullptr; c->d_anr_on = nullptr; c->anr_all = 0;
     if (f32) {
@@ -1405,6 +1410,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                 c->mfw_waves_per_cu = best;
                 if (best > 0) rc = dzalloc(ctx, (size_t)c->channels * kBqStateFloats, &c->d_bq_state_alt);
                 if (!rc && iirfold && !iirc.empty()) rc = upload(ctx, iirc, &c->d_mw_iir);
+                c->mfw_ssb_fold = iirfold && c->d_mw_iir; c->mfw_am_fold = amfold && c->d_mw_iir;
             }
         }
     }
@@ -1560,49 +1566,66 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         warm_tiles = (w + kTile - 1) / kTile;
         if (warm_tiles > 64 * (use_mfw ? 4 : 1)) can_split = false;
     }
-    long long nseg = 1;
-    if (c->time_segments == 1 || !can_split) nseg = 1;
-    else if (use_mfw && c->time_segments == 0) {
-        // one unit per wave, all units equally long: the launch takes ceil(units / resident waves) rounds of (segment + warm-up)
-        // tiles.  Pick the segment count that minimises that product (an exact multiple of the resident waves wins).
-        const long long slots = (long long)c->mfw_waves_per_cu * c->ctx->num_cus;
-        const long long max_nseg = std::max<long long>(1, tiles / std::max<long long>(4, 8 * warm_tiles));
-        const long long kmax = std::min<long long>(max_nseg, std::max<long long>(1, (8 * slots + c->channels - 1) / c->channels));
-        double best = 1e300;
-        for (long long k = 1; k <= kmax; k++) {
-            const long long st = (tiles + k - 1) / k, ns = (tiles + st - 1) / st;
-            const long long rounds = ((long long)c->channels * ns + slots - 1) / slots;
-            const double cost = (double)rounds * (double)(st + (ns > 1 ? warm_tiles : 0));
-            if (cost < best * 0.999) { best = cost; nseg = ns; }
+    // segment count for `nch` channels that are launched together
+    auto choose_nseg = [&](long long nch) -> long long {
+        long long ns_ = 1;
+        if (c->time_segments == 1 || !can_split || nch <= 0) return 1;
+        if (use_mfw && c->time_segments == 0) {
+            // one unit per wave, all units equally long: the launch takes ceil(units / resident waves) rounds of (segment + warm-up)
+            // tiles.  Pick the segment count that minimises that product (an exact multiple of the resident waves wins).
+            const long long slots = (long long)c->mfw_waves_per_cu * c->ctx->num_cus;
+            const long long max_nseg = std::max<long long>(1, tiles / std::max<long long>(4, 8 * warm_tiles));
+            const long long kmax = std::min<long long>(max_nseg, std::max<long long>(1, (8 * slots + nch - 1) / nch));
+            double best = 1e300;
+            for (long long k = 1; k <= kmax; k++) {
+                const long long st = (tiles + k - 1) / k, ns = (tiles + st - 1) / st;
+                const long long rounds = (nch * ns + slots - 1) / slots;
+                const double cost = (double)rounds * (double)(st + (ns > 1 ? warm_tiles : 0));
+                if (cost < best * 0.999) { best = cost; ns_ = ns; }
+            }
+        } else {
+            long long min_seg_tiles = std::max<long long>(4, 32 * warm_tiles);   // <= ~3 % redone work
+            long long max_nseg = std::max<long long>(1, tiles / min_seg_tiles);
+            long long want = c->time_segments > 1 ? c->time_segments : std::max<long long>(1, (2048 + nch - 1) / nch);
+            ns_ = std::max<long long>(1, std::min(want, max_nseg));
         }
-    } else {
-        long long min_seg_tiles = std::max<long long>(4, 32 * warm_tiles);   // <= ~3 % redone work
-        long long max_nseg = std::max<long long>(1, tiles / min_seg_tiles);
-        long long want = c->time_segments > 1 ? c->time_segments : std::max<long long>(1, (2048 + c->channels - 1) / c->channels);
-        nseg = std::max<long long>(1, std::min(want, max_nseg));
-    }
+        const long long st = (tiles + ns_ - 1) / ns_;
+        return (tiles + st - 1) / st;
+    };
+    long long nseg = choose_nseg(c->channels);
     long long seg_tiles = (tiles + nseg - 1) / nseg;
-    nseg = (tiles + seg_tiles - 1) / seg_tiles;
     p.nseg = (int)nseg; p.seg_len = seg_tiles * kTile; p.warm = (int)(nseg > 1 ? warm_tiles * kTile : 0);
 
     unsigned grid = (unsigned)(c->channels * nseg);
     if (use_mfw) {
         // unit table: (channel, segment) per wave; the waves of a workgroup share one tap table, so channels are grouped by
-        // table set and every group is padded to whole workgroups
+        // table set and every group is padded to whole workgroups.  SSB-table units and envelope-table units are two launches
+        // (two kernels), each with the segmentation that fills the GPU with its own channels.
         const int nw = c->mfw_nw;
-        if (c->units_mode_gen != c->mode_gen || c->units_nseg != nseg) {
+        if (c->units_mode_gen != c->mode_gen || c->units_tiles != tiles) {
             std::vector<uint32_t> order(c->channels);
             for (uint32_t i = 0; i < c->channels; i++) order[i] = i;
             auto fset_of = [&](uint32_t ch) { const int m = c->h_mode[ch]; return c->h_tapset[ch] * 3 + (m == MSDR_MODE_LSB ? 0 : m == MSDR_MODE_USB ? 1 : 2); };
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return fset_of(a) < fset_of(b); });
+            auto env_of = [&](uint32_t ch) { return fset_of(ch) % 3 == 2 ? 1 : 0; };
+            auto key_of = [&](uint32_t ch) { return env_of(ch) * 1000000 + fset_of(ch); };      // SSB tables first, envelope tables after
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key_of(a) < key_of(b); });
+            long long count[2] = {0, 0};
+            for (uint32_t ch : order) count[env_of(ch)]++;
+            for (int part = 0; part < 2; part++) {
+                c->part_nseg[part] = choose_nseg(count[part]);
+                c->part_seg_len[part] = ((tiles + c->part_nseg[part] - 1) / c->part_nseg[part]) * kTile;
+            }
             std::vector<int> units;
-            units.reserve(((size_t)c->channels * nseg + 3 * MSDR_MAX_TAPSETS * nw) * 2);
+            units.reserve(((size_t)c->channels * std::max(c->part_nseg[0], c->part_nseg[1]) + 3 * MSDR_MAX_TAPSETS * nw) * 2);
+            size_t ssb_units = 0;
             for (size_t i = 0; i < order.size(); i++) {
                 if (i > 0 && fset_of(order[i]) != fset_of(order[i - 1]))
                     while ((units.size() / 2) % nw) { units.push_back(-1); units.push_back(0); }
-                for (long long sg = 0; sg < nseg; sg++) { units.push_back((int)order[i]); units.push_back((int)sg); }
+                if (env_of(order[i]) && (i == 0 || !env_of(order[i - 1]))) ssb_units = units.size() / 2;      // first envelope-table unit
+                for (long long sg = 0; sg < c->part_nseg[env_of(order[i])]; sg++) { units.push_back((int)order[i]); units.push_back((int)sg); }
             }
             while ((units.size() / 2) % nw) { units.push_back(-1); units.push_back(0); }
+            if (order.empty() || !env_of(order.back())) ssb_units = units.size() / 2;                               // no envelope tables at all
             if (units.size() > c->units_cap) {
                 HIP_TRY(hipStreamSynchronize(c->ctx->stream));
                 hipFree(c->d_units); c->d_units = nullptr; c->units_cap = 0;
@@ -1611,8 +1634,11 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             }
             HIP_TRY(hipMemcpyAsync(c->d_units, units.data(), units.size() * sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));
             HIP_TRY(hipStreamSynchronize(c->ctx->stream));        // `units` is a local
-            c->units_mode_gen = c->mode_gen; c->units_nseg = nseg; c->units_wgs = (uint32_t)(units.size() / 2 / nw);
+            c->units_mode_gen = c->mode_gen; c->units_tiles = tiles; c->units_wgs = (uint32_t)(units.size() / 2 / nw);
+            c->units_wgs_ssb = (uint32_t)(ssb_units / nw);
         }
+        nseg = (c->units_wgs_ssb > 0) ? c->part_nseg[0] : c->part_nseg[1];            // reported by msdr_chain_get_info
+        p.warm = (int)(nseg > 1 ? warm_tiles * kTile : 0);
         grid = c->units_wgs;
         p.mf_units = c->d_units; p.mf_nw = nw; p.bq_state_out = c->d_bq_state_alt; p.mw_iir = c->d_mw_iir;
         { const char *e = getenv("MSDR_DBG"); p.dbg = e ? atoi(e) : 0; }
@@ -1635,12 +1661,28 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     unsigned block = kThreads;
     if (use_mfw) {
         block = (unsigned)c->mfw_nw * 64;
-        switch (c->nstages) {
-        case 0: hipLaunchKernelGGL(chain_mfw_kernel<0>, dim3(grid), dim3(block), lds, c->ctx->stream, p); break;
-        case 1: hipLaunchKernelGGL(chain_mfw_kernel<1>, dim3(grid), dim3(block), lds, c->ctx->stream, p); break;
-        case 2: hipLaunchKernelGGL(chain_mfw_kernel<2>, dim3(grid), dim3(block), lds, c->ctx->stream, p); break;
-        case 3: hipLaunchKernelGGL(chain_mfw_kernel<3>, dim3(grid), dim3(block), lds, c->ctx->stream, p); break;
-        default: hipLaunchKernelGGL(chain_mfw_kernel<4>, dim3(grid), dim3(block), lds, c->ctx->stream, p); break;
+        // SSB-table units and envelope-table units are separate launches of separate kernels (register allocation per flavour)
+        for (int part = 0; part < 2; part++) {
+            const unsigned g = part == 0 ? c->units_wgs_ssb : c->units_wgs - c->units_wgs_ssb;
+            if (g == 0) continue;
+            ChainParams q = p;
+            q.mf_units = c->d_units + (size_t)(part == 0 ? 0 : c->units_wgs_ssb) * c->mfw_nw * 2;
+            q.nseg = (int)c->part_nseg[part]; q.seg_len = c->part_seg_len[part]; q.warm = (int)(c->part_nseg[part] > 1 ? warm_tiles * kTile : 0);
+            const bool fold = part == 0 ? c->mfw_ssb_fold : c->mfw_am_fold;
+#define MSDR_MFW_LAUNCH(SS, AMF, FO) hipLaunchKernelGGL((chain_mfw_kernel<SS, AMF, FO>), dim3(g), dim3(block), lds, c->ctx->stream, q)
+#define MSDR_MFW_PLAIN(SS) do { if (part == 0) MSDR_MFW_LAUNCH(SS, false, false); else MSDR_MFW_LAUNCH(SS, true, false); } while (0)
+#define MSDR_MFW_FOLDS(SS) do { if (!fold) MSDR_MFW_PLAIN(SS); else if (part == 0) MSDR_MFW_LAUNCH(SS, false, true); else MSDR_MFW_LAUNCH(SS, true, true); } while (0)
+            switch (c->nstages) {
+            case 0: MSDR_MFW_PLAIN(0); break;
+            case 1: MSDR_MFW_FOLDS(1); break;
+            case 2: MSDR_MFW_FOLDS(2); break;
+            case 3: MSDR_MFW_PLAIN(3); break;
+            default: MSDR_MFW_PLAIN(4); break;
+            }
+#undef MSDR_MFW_FOLDS
+#undef MSDR_MFW_PLAIN
+#undef MSDR_MFW_LAUNCH
+            if (int rc = launch_check("chain_mfw_kernel")) return rc;
         }
         static const char *const names[5] = {"chain_mfw_kernel<0>", "chain_mfw_kernel<1>", "chain_mfw_kernel<2>", "chain_mfw_kernel<3>", "chain_mfw_kernel<4>"};
         kname = names[c->nstages];

@@ -455,6 +455,15 @@ def main():
         r["mfma_f16_tflops_executed"] = round(mf * samples_per_step / (k_ms * 1e-3) / 1e12, 1)
         r["mfma_f16_frac"] = round(mf * samples_per_step / (k_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
         r["mfma_f16_peak_tflops"] = MFMA_F16_PEAK_TFLOPS
+    # HBM traffic per launch of the dominant kernel: the PMC passes cannot run inside this process (rocprofv3 wraps the command), so
+    # the figure is the one tools/profile.sh measured for this workload and committed under profiles/ (FETCH_SIZE x 1024 x 2 +
+    # WRITE_SIZE x 1024, corrected as MI355X_MICROARCH.md prescribes); null when no such profile is there or the shape was overridden
+    prof = os.path.join(ROOT, "profiles", "r01", "%s_rocprof_summary.txt" % args.workload)
+    if os.path.exists(prof) and not (args.samples or args.channels or args.taps or args.stages >= 0 or q15 or args.no_mfma):
+        for line in open(prof):
+            if line.startswith("HBM traffic per chain_kernel launch") and "total" in line:
+                out["roofline"]["traffic"] = float(line.rsplit("total", 1)[1].split()[0])
+                out["roofline"]["traffic_source"] = "profiles/r01/%s_rocprof_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % args.workload
     if gather:
         out["gather"] = gather
     if not args.no_cpu and world == 1:

@@ -825,3 +825,179 @@ void orc_dac_format(const int16_t *src, int16_t *dest, uint32_t n)
 {
     for (uint32_t i = 0; i < n; i++) dest[i] = src ? (int16_t)(((int32_t)src[i] + 32768) >> 4) : (int16_t)2048;
 }
+
+/* ======================================================================================
+ * Row f4 (second half): the spectrum display's FFT, UI.cpp:520-592.
+ *   initSpectrum()  : arm_rfft_init_q15(&FFT, 128, 0, 1)            (UI.cpp:522-524)
+ *   showSpectrum()  : every 25th call (:534-536) arm_rfft_q15(&FFT, data, FFT_out) (:551),
+ *                     then 127 column heights y_new = abs(FFT_out[127 - x]) / 200, clipped to
+ *                     16, y1_new = 15 - y_new (:557-572).  The drawing calls are the OLED driver.
+ * arm_rfft_q15 forward (arm_rfft_q15.c:74-112) = arm_cfft_q15(len 64) in place on the 128 reals
+ * taken as 64 complex (re = even sample) + arm_split_rfft_q15.  arm_cfft_q15 for 64 points
+ * (arm_cfft_q15.c:106-127) = arm_radix4_butterfly_q15(p, 64, twiddleCoef_64_q15, 1) +
+ * arm_bitreversal_16 (ARM assembly, arm_bitreversal2.S:117-139: for each pair of table entries
+ * (a, b) swap the 32-bit words at byte offsets a/2 and b/2).  The Cortex-M4 (ARM_MATH_DSP)
+ * branches are the ones restated: arm_cfft_radix4_q15.c:156-611, arm_rfft_q15.c:152-222.
+ * Every packed 2x16-bit intrinsic is written out per half with the semantics of the
+ * reference header's generic-C definitions (arm_math.h:721-991).
+ * PINNED: butterfly+bit reversal against the compiled arm_cfft_radix4_q15 (the reference's all-C
+ * entry to the same butterfly), the split against the compiled arm_split_rfft_q15, the tables
+ * against the compiled arm_common_tables.c / arm_rfft_init_q15.c (tests/test_oracle_pinned.py).
+ * ====================================================================================== */
+typedef struct { int32_t re, im; } cq15;   /* one packed word: re = low half, im = high half */
+static inline int32_t top16(int32_t v) { return (int32_t)(int16_t)((uint32_t)v >> 16); }
+static inline int32_t mul_wrap(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+/* re' = (c*re + s*im) >> 16, im' = (c*im - s*re) >> 16: __SMUAD(C, X) >> 16 and the high half of __SMUSDX(C, X) */
+static inline cq15 twid(cq15 x, int32_t c, int32_t s)
+{
+    cq15 r;
+    r.re = top16(wrap_add32(mul_wrap(c, x.re), mul_wrap(s, x.im)));
+    r.im = top16((int32_t)((uint32_t)mul_wrap(c, x.im) - (uint32_t)mul_wrap(s, x.re)));
+    return r;
+}
+static inline cq15 cq_ld(const int16_t *p, uint32_t i) { cq15 r = { p[2 * i], p[2 * i + 1] }; return r; }
+static inline void cq_st(int16_t *p, uint32_t i, cq15 v) { p[2 * i] = (int16_t)v.re; p[2 * i + 1] = (int16_t)v.im; }
+static inline cq15 cq_sar(cq15 a, int k) { cq15 r = { a.re >> k, a.im >> k }; return r; }
+static inline cq15 cq_qadd(cq15 a, cq15 b) { cq15 r = { ssat16(a.re + b.re), ssat16(a.im + b.im) }; return r; }
+static inline cq15 cq_qsub(cq15 a, cq15 b) { cq15 r = { ssat16(a.re - b.re), ssat16(a.im - b.im) }; return r; }
+
+void orc_fft_tables(int16_t twiddle64[96], int16_t coefA[128], int16_t coefB[128])
+{
+    /* twiddleCoef_64_q15 (arm_common_tables.c:12914): {cos, sin}(2 pi i / 64), i < 48, floor(x * 2^15) clipped;
+     * realCoefAQ15 / realCoefBQ15 (arm_rfft_init_q15.c:44-56, :1086-1098) at the 128-point stride 64:
+     * A = {0.5 (1 - sin), -0.5 cos}, B = {0.5 (1 + sin), 0.5 cos} of 2 pi i / 128, round(x * 2^15). */
+    const double pi = 3.14159265358979323846;
+    for (int i = 0; i < 48; i++) {
+        double c = floor(cos(2.0 * pi * i / 64.0) * 32768.0 + 1e-6), s = floor(sin(2.0 * pi * i / 64.0) * 32768.0 + 1e-6);
+        twiddle64[2 * i] = (int16_t)(c > 32767.0 ? 32767.0 : c);
+        twiddle64[2 * i + 1] = (int16_t)(s > 32767.0 ? 32767.0 : s);
+    }
+    for (int i = 0; i < 64; i++) {
+        double sn = sin(2.0 * pi * i / 128.0), cs = cos(2.0 * pi * i / 128.0);
+        const double v[4] = { 0.5 * (1.0 - sn), -0.5 * cs, 0.5 * (1.0 + sn), 0.5 * cs };
+        int16_t q[4];
+        for (int k = 0; k < 4; k++) { double r = floor(v[k] * 32768.0 + 0.5); q[k] = (int16_t)(r > 32767.0 ? 32767.0 : r); }   /* B[64] = 0x7fff */
+        coefA[2 * i] = q[0]; coefA[2 * i + 1] = q[1]; coefB[2 * i] = q[2]; coefB[2 * i + 1] = q[3];
+    }
+}
+
+/* armBitRevIndexTable_fixed_64 (arm_common_tables.c:17129) as a set: 28 pairs of byte offsets 8*i, 8*rev6(i). */
+uint32_t orc_bitrev_table64(uint16_t table[56])
+{
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < 64; i++) {
+        uint32_t r = 0;
+        for (int b = 0; b < 6; b++) r |= ((i >> b) & 1u) << (5 - b);
+        if (i < r) { table[n++] = (uint16_t)(8 * i); table[n++] = (uint16_t)(8 * r); }
+    }
+    return n;
+}
+/* arm_bitreversal2.S:117-139 */
+void orc_bitreversal_16(int16_t *buf, uint32_t bitRevLen, const uint16_t *table)
+{
+    uint32_t *w = (uint32_t *)buf;
+    for (uint32_t k = 0; k < (bitRevLen + 1) / 2; k++) {
+        uint32_t a = (table[2 * k] >> 1) / 4, b = (table[2 * k + 1] >> 1) / 4, t = w[a];
+        w[a] = w[b]; w[b] = t;
+    }
+}
+
+/* arm_cfft_radix4_q15.c:156-611 for fftLen = 64, twidCoefModifier = 1, in place, output in bit-reversed order */
+void orc_radix4_butterfly64_q15(int16_t *p, const int16_t *tw)
+{
+    /* first stage (:168-365): inputs >> 2, 16 butterflies over (j, j+16, j+32, j+48), twiddle index j */
+    for (uint32_t j = 0; j < 16; j++) {
+        cq15 a = cq_sar(cq_ld(p, j), 2), b = cq_sar(cq_ld(p, j + 16), 2), c = cq_sar(cq_ld(p, j + 32), 2), d = cq_sar(cq_ld(p, j + 48), 2);
+        cq15 R = cq_qadd(a, c), S = cq_qsub(a, c), T = cq_qadd(b, d), o, V;
+        o.re = (R.re + T.re) >> 1; o.im = (R.im + T.im) >> 1;                /* __SHADD16(R, T) :239 */
+        cq_st(p, j, o);
+        R = cq_qsub(R, T);
+        cq_st(p, j + 16, twid(R, tw[4 * j], tw[4 * j + 1]));                /* co2/si2 :246-275 */
+        T = cq_qsub(b, d);
+        V.re = ssat16(S.re - T.im); V.im = ssat16(S.im + T.re);             /* __QASX(S, T) :290 */
+        S.re = ssat16(S.re + T.im); S.im = ssat16(S.im - T.re);             /* __QSAX(S, T) :292 */
+        cq_st(p, j + 32, twid(S, tw[2 * j], tw[2 * j + 1]));                /* co1/si1 :300-323 */
+        cq_st(p, j + 48, twid(V, tw[6 * j], tw[6 * j + 1]));                /* co3/si3 :326-349 */
+    }
+    /* middle stage (:371-517), once for 64 points: n1 = 16, n2 = 4, twiddle index 4 j */
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t ic = 4 * j;
+        for (uint32_t i0 = j; i0 < 64; i0 += 16) {
+            cq15 a = cq_ld(p, i0), b = cq_ld(p, i0 + 4), c = cq_ld(p, i0 + 8), d = cq_ld(p, i0 + 12);
+            cq15 R = cq_qadd(a, c), S = cq_qsub(a, c), T = cq_qadd(b, d), o, V;
+            o.re = ((R.re + T.re) >> 1) >> 1; o.im = ((R.im + T.im) >> 1) >> 1;   /* __SHADD16 twice :421-423 */
+            cq_st(p, i0, o);
+            R.re = (R.re - T.re) >> 1; R.im = (R.im - T.im) >> 1;           /* __SHSUB16 :427 */
+            cq_st(p, i0 + 4, twid(R, tw[4 * ic], tw[4 * ic + 1]));
+            T = cq_qsub(b, d);
+            V.re = (S.re - T.im) >> 1; V.im = (S.im + T.re) >> 1;           /* __SHASX(S, T) :465 */
+            S.re = (S.re + T.im) >> 1; S.im = (S.im - T.re) >> 1;           /* __SHSAX(S, T) :468 */
+            cq_st(p, i0 + 8, twid(S, tw[2 * ic], tw[2 * ic + 1]));
+            cq_st(p, i0 + 12, twid(V, tw[6 * ic], tw[6 * ic + 1]));
+        }
+    }
+    /* last stage (:530-607): 16 groups of four neighbours, no twiddles; stores a', c', b', d' */
+    for (uint32_t g = 0; g < 16; g++) {
+        cq15 a = cq_ld(p, 4 * g), b = cq_ld(p, 4 * g + 1), c = cq_ld(p, 4 * g + 2), d = cq_ld(p, 4 * g + 3);
+        cq15 R = cq_qadd(a, c), T = cq_qadd(b, d), S = cq_qsub(a, c), U = cq_qsub(b, d), o;
+        o.re = (R.re + T.re) >> 1; o.im = (R.im + T.im) >> 1; cq_st(p, 4 * g, o);
+        o.re = (R.re - T.re) >> 1; o.im = (R.im - T.im) >> 1; cq_st(p, 4 * g + 1, o);
+        o.re = (S.re + U.im) >> 1; o.im = (S.im - U.re) >> 1; cq_st(p, 4 * g + 2, o);   /* __SHSAX(S, U) :585 */
+        o.re = (S.re - U.im) >> 1; o.im = (S.im + U.re) >> 1; cq_st(p, 4 * g + 3, o);   /* __SHASX(S, U) :589 */
+    }
+}
+
+/* arm_rfft_q15.c:128-222 (ARM_MATH_DSP branch), fftLen = 64 complex points, modifier applied by the caller's tables:
+ * A/B = 64 {re, im} pairs (index i = the reference's pATable[2 * modifier * i]).  pDst gets 256 int16. */
+void orc_split_rfft64_q15(const int16_t *X, const int16_t *A, const int16_t *B, int16_t *dst)
+{
+    for (uint32_t i = 1; i < 64; i++) {
+        const int32_t r1 = X[2 * i], i1 = X[2 * i + 1], r2 = X[2 * (64 - i)], i2 = X[2 * (64 - i) + 1];
+        const int32_t a0 = A[2 * i], a1 = A[2 * i + 1], b0 = B[2 * i], b1 = B[2 * i + 1];
+        uint32_t outR = (uint32_t)mul_wrap(r1, a0) - (uint32_t)mul_wrap(i1, a1);                      /* __SMUSD :173 */
+        outR = (outR + (uint32_t)mul_wrap(r2, b0) + (uint32_t)mul_wrap(i2, b1)) >> 16;                /* __SMLAD ... >> 16U :186 */
+        uint32_t outI = (uint32_t)mul_wrap(r2, b1) - (uint32_t)mul_wrap(i2, b0);                      /* __SMUSDX :193 */
+        outI = outI + (uint32_t)mul_wrap(r1, a1) + (uint32_t)mul_wrap(i1, a0);                        /* __SMLADX :202 */
+        const int32_t im = (int32_t)outI >> 16;
+        dst[2 * i] = (int16_t)outR; dst[2 * i + 1] = (int16_t)im;                                     /* :205-206 */
+        dst[256 - 2 * i] = (int16_t)outR; dst[256 - 2 * i + 1] = (int16_t)(-im);                      /* :209-211 */
+    }
+    dst[128] = (int16_t)(((int32_t)X[0] - X[1]) >> 1); dst[129] = 0;                                  /* :218-219 */
+    dst[0] = (int16_t)(((int32_t)X[0] + X[1]) >> 1); dst[1] = 0;                                      /* :221-222 */
+}
+
+/* arm_rfft_q15(&FFT, data, FFT_out) with FFT = (128, forward, bit reversal on).  `data` is left untouched here
+ * (the reference transforms it in place, a latent bug: the mixer reads the block afterwards);
+ * work[128] receives what the reference leaves in `data`. */
+void orc_rfft128_q15(const int16_t *data, int16_t *fft_out /* 256 */, int16_t *work /* 128 or NULL */)
+{
+    int16_t tw[96], A[128], B[128], buf[128];
+    uint16_t brt[56];
+    orc_fft_tables(tw, A, B);
+    const uint32_t nbr = orc_bitrev_table64(brt);
+    memcpy(buf, data, sizeof buf);
+    orc_radix4_butterfly64_q15(buf, tw);
+    orc_bitreversal_16(buf, nbr, brt);
+    orc_split_rfft64_q15(buf, A, B, fft_out);
+    if (work) memcpy(work, buf, sizeof buf);
+}
+
+/* UI.cpp:557-572: y_new[x] = min(abs(FFT_out[127 - x]) / 200, 16) for x = 0..126 (int arithmetic: abs(-32768) = 32768) */
+void orc_spectrum_columns(const int16_t *fft_out, uint8_t *y_new /* 127 */)
+{
+    for (int x = 0; x < 127; x++) {
+        int v = fft_out[127 - x];
+        int y = (v < 0 ? -v : v) / 200;
+        y_new[x] = (uint8_t)(y > 16 ? 16 : y);
+    }
+}
+
+/* showSpectrum's cadence (UI.cpp:534-536): `if (!Spectrum_on) return; if (--spectrumCounter > 0) return; spectrumCounter = 25;`
+ * returns 1 when this call computes a spectrum. */
+int orc_spectrum_tick(int spectrum_on, int *counter)
+{
+    if (!spectrum_on) return 0;
+    if (--*counter > 0) return 0;
+    *counter = 25;
+    return 1;
+}

@@ -232,6 +232,19 @@ void orc_anr_q15(orc_anr *a, int anr_on, int16_t *data, uint32_t n);
  * ((sample) + 32768) >> 4 per sample; 2048 (mid-scale) when no block arrived.  UNPINNED (needs the Teensyduino core). */
 void orc_dac_format(const int16_t *src /* NULL = no block */, int16_t *dest, uint32_t n);
 
+/* ---- Row f4 (second half): the spectrum display's 128-point q15 real FFT, UI.cpp:520-592 -> arm_rfft_q15.c,
+ * arm_cfft_q15.c, arm_cfft_radix4_q15.c (ARM_MATH_DSP branches), arm_bitreversal2.S.  PINNED stage by stage against the
+ * compiled reference (oracle/_ref): butterfly + bit reversal vs arm_cfft_radix4_q15, split vs arm_split_rfft_q15, tables
+ * vs arm_common_tables.c / arm_rfft_init_q15.c; the column heights (UI.cpp:557-572) are three lines, unpinned. */
+void orc_fft_tables(int16_t twiddle64[96], int16_t coefA[128], int16_t coefB[128]);
+uint32_t orc_bitrev_table64(uint16_t table[56]);
+void orc_bitreversal_16(int16_t *buf, uint32_t bitRevLen, const uint16_t *table);
+void orc_radix4_butterfly64_q15(int16_t *p, const int16_t *tw);
+void orc_split_rfft64_q15(const int16_t *X, const int16_t *A, const int16_t *B, int16_t *dst);
+void orc_rfft128_q15(const int16_t *data, int16_t *fft_out /* 256 */, int16_t *work /* 128 or NULL */);
+void orc_spectrum_columns(const int16_t *fft_out, uint8_t *y_new /* 127 */);
+int orc_spectrum_tick(int spectrum_on, int *counter);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,6 +145,24 @@ def main():
             if mn in ("AM", "CW"):
                 g["chain/%s_%s_audio_q31" % (sn, mn)] = np_demod(mode, fi, fq, ref, orclib.SQRT_Q31)
 
+    # ---- F6 spectrum FFT (row f4): reference tables as data + known answers of the compiled stages ----
+    g["fft/twiddleCoef_64_q15"] = ref.table("twiddleCoef_64_q15", 96)
+    g["fft/armBitRevIndexTable_fixed_64"] = ref.table("armBitRevIndexTable_fixed_64", 56, orclib.C.c_uint16)
+    g["fft/realCoefAQ15_stride64"] = ref.table("realCoefAQ15", 8192).reshape(-1, 2)[::64].reshape(-1).copy()
+    g["fft/realCoefBQ15_stride64"] = ref.table("realCoefBQ15", 8192).reshape(-1, 2)[::64].reshape(-1).copy()
+    rng = np.random.default_rng(64)
+    n128 = np.arange(128)
+    fx = [sig["am"][:128], sig["tones"][128:256], sig["noise"][:128], sig["full"][:128],
+          np.full(128, -32768, np.int16), np.full(128, 32767, np.int16),
+          (8000 * np.sin(2 * np.pi * 10 * n128 / 128)).astype(np.int16),
+          (30000 * np.cos(2 * np.pi * 32 * n128 / 128)).astype(np.int16),
+          np.where(n128 & 1, -32768, 32767).astype(np.int16), np.zeros(128, np.int16)]
+    fx += [rng.integers(-a, a + 1, 128).astype(np.int16) for a in (3, 200, 5000, 32767) for _ in range(4)]
+    fx = np.stack(fx)
+    g["fft/x"] = fx
+    g["fft/rfft128_out"] = np.stack([ref.rfft128_q15(x)[0] for x in fx])
+    g["fft/rfft128_work"] = np.stack([ref.rfft128_q15(x)[1] for x in fx])
+
     path = os.path.join(HERE, "golden.npz")
     np.savez_compressed(path, **g)
     for k, v in g.items():

@@ -282,6 +282,28 @@ class Oracle:
         assert b.size == BLOCK
         self.lib.orc_agc_block(C.byref(a), _ptr(b))
 
+    def fft_tables(self):
+        tw, a, b = np.zeros(96, np.int16), np.zeros(128, np.int16), np.zeros(128, np.int16)
+        self.lib.orc_fft_tables(_ptr(tw), _ptr(a), _ptr(b))
+        return tw, a, b
+
+    def bitrev_table64(self):
+        t = np.zeros(56, np.uint16)
+        n = self.lib.orc_bitrev_table64(_ptr(t))
+        return t[:n]
+
+    def rfft128_q15(self, x):
+        x = np.ascontiguousarray(x, np.int16)
+        out, work = np.zeros(256, np.int16), np.zeros(128, np.int16)
+        self.lib.orc_rfft128_q15(_ptr(x), _ptr(out), _ptr(work))
+        return out, work
+
+    def spectrum_columns(self, fft_out):
+        fft_out = np.ascontiguousarray(fft_out, np.int16)
+        y = np.zeros(127, np.uint8)
+        self.lib.orc_spectrum_columns(_ptr(fft_out), _ptr(y))
+        return y
+
     def calc_fir_coeffs(self, n, fc, astop=70.0, ftype=0, dfc=0.0, fs=24000.0, pi_double=False, room=None):
         self.lib.orc_set_pi_double(int(pi_double))
         buf = np.zeros(room or (2 * n + 8), np.int16)
@@ -379,6 +401,11 @@ class Oracle:
         return out, used
 
 
+class ArmCfftRadix4Q15(C.Structure):   # arm_math.h:1963-1972 (arm_cfft_radix4_instance_q15)
+    _fields_ = [("fftLen", C.c_uint16), ("ifftFlag", C.c_uint8), ("bitReverseFlag", C.c_uint8), ("pTwiddle", _p),
+                ("pBitRevTable", _p), ("twidCoefModifier", C.c_uint16), ("bitRevFactor", C.c_uint16)]
+
+
 class ArmFirQ15(C.Structure):     # arm_math.h:1027-1032
     _fields_ = [("numTaps", C.c_uint16), ("pState", _p), ("pCoeffs", _p)]
 
@@ -439,3 +466,28 @@ class Reference:
         f = self.lib.calc_FIR_coeffs_pid if pi_double else self.lib.calc_FIR_coeffs
         f(_ptr(buf), int(n), float(fc), float(astop), int(ftype), float(dfc), float(fs))
         return buf
+
+    # ---- row f4: the q15 FFT pieces (see oracle/build_ref.sh for what is and is not buildable) ----
+    def table(self, name, n, ctype=C.c_int16):
+        return np.array((ctype * n).in_dll(self.lib, name))
+
+    def cfft64_q15(self, x):
+        """arm_cfft_radix4_q15 (64 points, forward, bit reversal on): the reference's all-C entry to
+        arm_radix4_butterfly_q15, in place on 64 {re, im} int16 pairs."""
+        S = ArmCfftRadix4Q15()
+        rc = self.lib.arm_cfft_radix4_init_q15(C.byref(S), C.c_uint16(64), C.c_uint8(0), C.c_uint8(1))
+        assert rc == 0
+        buf = np.ascontiguousarray(x, np.int16).copy()
+        self.lib.arm_cfft_radix4_q15(C.byref(S), _ptr(buf))
+        return buf
+
+    def rfft128_q15(self, x):
+        """What arm_rfft_q15(&FFT(128, 0, 1), x, out) computes, composed from the compiled stages (arm_rfft_q15
+        itself needs the assembly-only arm_bitreversal_16): returns (out[256], x_after[128])."""
+        if not hasattr(self, "_coefA"):
+            self._coefA = self.table("realCoefAQ15", 8192)
+            self._coefB = self.table("realCoefBQ15", 8192)
+        work = self.cfft64_q15(x)
+        out = np.zeros(256, np.int16)
+        self.lib.arm_split_rfft_q15(_ptr(work), C.c_uint32(64), _ptr(self._coefA), _ptr(self._coefB), _ptr(out), C.c_uint32(64))
+        return out, work

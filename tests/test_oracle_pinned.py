@@ -144,3 +144,60 @@ def test_static_tables_properties(golden):
     for a, b, s in (("FIR_SSB_I_coeffs", "FIR_SSB_Q_coeffs", 59369), ("FIR_CW_I_coeffs", "FIR_CW_Q_coeffs", 42358)):
         assert np.array_equal(golden["taps/" + a], golden["taps/" + b][::-1])
         assert np.abs(golden["taps/" + a].astype(int)).sum() == s
+
+
+# ---------------------------------------------------------------- row f4: spectrum FFT -----
+def test_fft_tables_match_golden(orc, golden):
+    """Generated twiddle / split-coefficient / bit-reversal tables == the reference's tables (data fixtures)."""
+    tw, a, b = orc.fft_tables()
+    assert np.array_equal(tw, golden["fft/twiddleCoef_64_q15"])
+    assert np.array_equal(a, golden["fft/realCoefAQ15_stride64"])
+    assert np.array_equal(b, golden["fft/realCoefBQ15_stride64"])
+    pairs = lambda t: sorted((min(p), max(p)) for p in np.asarray(t, int).reshape(-1, 2).tolist())
+    assert pairs(orc.bitrev_table64()) == pairs(golden["fft/armBitRevIndexTable_fixed_64"])
+
+
+def test_rfft128_matches_golden(orc, golden):
+    for x, want, work in zip(golden["fft/x"], golden["fft/rfft128_out"], golden["fft/rfft128_work"]):
+        out, w = orc.rfft128_q15(x)
+        assert np.array_equal(w, work)       # butterflies + bit reversal (what the reference leaves in `data`)
+        assert np.array_equal(out, want)     # split stage
+
+
+def test_rfft128_matches_reference_live(orc, ref):
+    rng = np.random.default_rng(128)
+    for case in range(300):
+        amp = (300, 8000, 32767, 32767)[case % 4]
+        x = rng.integers(-amp, amp + 1, 128).astype(np.int16)
+        if case % 4 == 3:
+            x[rng.integers(0, 128, 40)] = -32768
+            x[rng.integers(0, 128, 40)] = 32767
+        want, work = ref.rfft128_q15(x)
+        out, w = orc.rfft128_q15(x)
+        assert np.array_equal(w, work) and np.array_equal(out, want), case
+
+
+def test_rfft128_is_a_dft(orc):
+    """Independent of the reference: out[2k], out[2k+1] ~ Re, Im of (1/128) sum x[n] e^{-2 pi i k n / 128} (CMSIS scales
+    the input down by 2 per radix-2 stage and the split halves once more) within the fixed-point noise."""
+    rng = np.random.default_rng(5)
+    x = rng.integers(-20000, 20001, 128).astype(np.int16)
+    out, _ = orc.rfft128_q15(x)
+    F = np.fft.fft(x.astype(float)) / 128
+    got = out[0::2].astype(float) + 1j * out[1::2].astype(float)
+    assert np.max(np.abs(got[1:64] - F[1:64])) < 6.0
+    assert np.max(np.abs(got[65:] - F[65:])) < 6.0
+
+
+def test_spectrum_columns_second_model(orc, golden):
+    for out in golden["fft/rfft128_out"]:
+        v = np.abs(out[127:0:-1].astype(np.int32)) // 200
+        assert np.array_equal(orc.spectrum_columns(out), np.minimum(v, 16).astype(np.uint8))
+
+
+def test_spectrum_tick_cadence(orc):
+    import ctypes as C
+    cnt = C.c_int(0)               # spectrumCounter starts at 0 -> first call draws, then every 25th
+    hits = [i for i in range(80) if orc.lib.orc_spectrum_tick(1, C.byref(cnt))]
+    assert hits == [0, 25, 50, 75]
+    assert orc.lib.orc_spectrum_tick(0, C.byref(cnt)) == 0

@@ -218,6 +218,35 @@ int msdr_anr_reset(msdr_anr *A);
 int msdr_anr_get_state(msdr_anr *A, uint32_t channel, float state[MSDR_ANR_STATE_FLOATS]);
 int msdr_anr_destroy(msdr_anr *A);
 
+/* ======================================================================================
+ * SURVEY.md 8(f4), second half: the spectrum display's FFT (UI.cpp:520-592).
+ *   msdr_rfft128_q15       <-> arm_rfft_q15(&FFT, data, FFT_out) with FFT = arm_rfft_init_q15(&FFT, 128, 0, 1) (UI.cpp:523,
+ *                              :551; arm_rfft_q15.c:74-112, Cortex-M4 branches), batched: transform f reads 128 int16 at
+ *                              d_src + f * src_stride (src_stride a multiple of 8 samples, d_src 16-byte aligned) and writes
+ *                              d_fft_out[f][256] (interleaved re, im of 128 bins, the upper half the conjugate mirror) and/or
+ *                              d_columns[f][128] = the 127 column heights showSpectrum draws,
+ *                              y_new[x] = min(abs(FFT_out[127 - x]) / 200, 16) (UI.cpp:557-572), entry 127 = 0.
+ *                              Either output may be NULL.  Unlike the reference, d_src is NOT transformed in place.
+ *   msdr_rfft_q15_init_check   the argument check of arm_rfft_init_q15 (arm_rfft_init_q15.c:2154-2225): SUCCESS for
+ *                              fftLenReal in {32 .. 8192} powers of two, else ARGUMENT_ERROR; this library runs 128 forward
+ *                              with bit reversal only (what initSpectrum asks for) and reports other valid sizes as
+ *                              MSDR_STATUS_LENGTH_ERROR.
+ *   msdr_spectrum_*        <-> initSpectrum() / showSpectrum(): Spectrum_on, and spectrumCounter's "every 25th call"
+ *                              cadence (UI.cpp:122, :534-536; the first call after create draws).  *drawn = 1 when this
+ *                              call computed a spectrum (outputs written), 0 when it returned early like the reference.
+ *   msdr_rfft128_tables    host side, no device: the constant tables the transform uses, regenerated from their documented
+ *                              formulas -- twiddleCoef_64_q15[96] | realCoefAQ15 pairs at stride 64 [128] | realCoefBQ15 ditto [128]
+ *                              (arm_common_tables.c:12914, arm_rfft_init_q15.c:44-56, :1086-1098).
+ */
+void msdr_rfft128_tables(int16_t tables[352]);
+int msdr_rfft_q15_init_check(uint32_t fftLenReal, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+int msdr_rfft128_q15(msdr_ctx *ctx, const q15_t *d_src, uint64_t src_stride, q15_t *d_fft_out, uint8_t *d_columns, uint32_t nfft);
+typedef struct msdr_spectrum msdr_spectrum;
+int msdr_spectrum_create(msdr_ctx *ctx, uint32_t channels, msdr_spectrum **out);
+int msdr_spectrum_set_on(msdr_spectrum *S, int spectrum_on);
+int msdr_spectrum_show(msdr_spectrum *S, const q15_t *d_data, uint64_t channel_stride, q15_t *d_fft_out, uint8_t *d_columns, int *drawn);
+int msdr_spectrum_destroy(msdr_spectrum *S);
+
 /* Stateless per-block stages. */
 /* what AudioOutputAnalog::isr writes to the 12-bit DAC, output_dac.cpp:139-151: (sample + 32768) >> 4;
  * d_src == NULL = no block arrived: 2048 (mid-scale).  d_dest may alias d_src. */

@@ -10,6 +10,7 @@
 #include "msdr_chain_mfma.hiph"
 #include "msdr_chain_mfw.hiph"
 #include "msdr_frontend.hiph"
+#include "msdr_spectrum.hiph"
 #include "msdr_design.h"
 
 #include <algorithm>
@@ -61,6 +62,7 @@ struct msdr_ctx {
     int num_cus;
     void *scratch;          // small device buffer reused for per-call host tables (oscillator tables)
     size_t scratch_bytes;
+    int16_t *d_fft_tables;  // twiddle / split tables of the 128-point q15 real FFT, created on first use
 };
 
 static int bind(msdr_ctx *ctx)
@@ -99,7 +101,7 @@ extern "C" int msdr_ctx_create(int device, void *hip_stream, msdr_ctx **out)
     msdr_ctx *c = new (std::nothrow) msdr_ctx();
     if (!c) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
     c->device = device; c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    c->scratch = nullptr; c->scratch_bytes = 0;
+    c->scratch = nullptr; c->scratch_bytes = 0; c->d_fft_tables = nullptr;
     c->owns_stream = (hip_stream == nullptr);
     c->stream = (hipStream_t)hip_stream;
     if (c->owns_stream) {
@@ -116,6 +118,7 @@ extern "C" int msdr_ctx_destroy(msdr_ctx *ctx)
     if (int rc = bind(ctx)) return rc;
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->d_fft_tables) (void)hipFree(ctx->d_fft_tables);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -559,6 +562,7 @@ static int freqconv_common(msdr_ctx *ctx, T *d_i, T *d_q, const T *osc_i, const 
     if (ctx->scratch_bytes < need) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->d_fft_tables) (void)hipFree(ctx->d_fft_tables);
         ctx->scratch = nullptr; ctx->scratch_bytes = 0;
         HIP_TRY(hipMalloc(&ctx->scratch, std::max<size_t>(need, 4096)));
         ctx->scratch_bytes = std::max<size_t>(need, 4096);
@@ -858,6 +862,81 @@ extern "C" int msdr_dac_format_q15(msdr_ctx *ctx, const q15_t *d_src, q15_t *d_d
     if (!d_dest) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
     hipLaunchKernelGGL(dac_format_kernel, dim3(grid_1d((total + 7) / 8)), dim3(256), 0, ctx->stream, (const short *)d_src, (short *)d_dest, total);
     return launch_check("dac_format_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// row f4: spectrum FFT (UI.cpp:520-592)
+// ------------------------------------------------------------------------------------------------
+extern "C" void msdr_rfft128_tables(int16_t tables[352]) { msdr::design::fft128_tables(tables); }
+extern "C" int msdr_rfft_q15_init_check(uint32_t fftLenReal, uint32_t ifftFlagR, uint32_t bitReverseFlag)
+{
+    bool valid = false;
+    for (uint32_t n = 32; n <= 8192; n <<= 1) valid |= (n == fftLenReal);      // arm_rfft_init_q15.c:2179-2221
+    if (!valid) return fail(MSDR_STATUS_ARGUMENT_ERROR, "fftLenReal %u is not a supported RFFT length", fftLenReal);
+    if (fftLenReal != 128 || ifftFlagR != 0 || bitReverseFlag != 1)
+        return fail(MSDR_STATUS_LENGTH_ERROR, "only the 128-point forward transform with bit reversal (initSpectrum, UI.cpp:523) is built");
+    return 0;
+}
+extern "C" int msdr_rfft128_q15(msdr_ctx *ctx, const q15_t *d_src, uint64_t src_stride, q15_t *d_fft_out, uint8_t *d_columns, uint32_t nfft)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (nfft == 0) return 0;
+    if (!d_src) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    if ((src_stride & 7) || (reinterpret_cast<uintptr_t>(d_src) & 15) || (reinterpret_cast<uintptr_t>(d_fft_out) & 15) ||
+        (reinterpret_cast<uintptr_t>(d_columns) & 7))
+        return fail(MSDR_STATUS_ARGUMENT_ERROR, "rfft128: src/fft_out must be 16-byte aligned, columns 8-byte aligned, src_stride a multiple of 8");
+    if (nfft > 1 && src_stride < 128) return fail(MSDR_STATUS_ARGUMENT_ERROR, "rfft128: src_stride < 128 with more than one transform");
+    if (!ctx->d_fft_tables) {
+        std::vector<int16_t> h(kFftTableShorts);
+        msdr::design::fft128_tables(h.data());
+        if (int rc = upload(ctx, h, &ctx->d_fft_tables)) return rc;
+    }
+    if (!d_fft_out && !d_columns) return 0;
+    const int grid = (int)std::min<long long>(((long long)nfft + kFftPerBlock - 1) / kFftPerBlock, 256LL * 32);
+    hipLaunchKernelGGL(spectrum_rfft128_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const short *)d_src, (long long)src_stride,
+                       (short *)d_fft_out, (unsigned char *)d_columns, (const short *)ctx->d_fft_tables, (int)nfft);
+    return launch_check("spectrum_rfft128_kernel");
+}
+
+struct msdr_spectrum {
+    msdr_ctx *ctx;
+    uint32_t channels;
+    int spectrum_on;        // Spectrum_on
+    int counter;            // spectrumCounter (UI.cpp:122: starts at 0, so the first call draws)
+};
+extern "C" int msdr_spectrum_create(msdr_ctx *ctx, uint32_t channels, msdr_spectrum **out)
+{
+    if (!out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "out is null");
+    *out = nullptr;
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = msdr_rfft_q15_init_check(128, 0, 1)) return rc;                 // initSpectrum(), UI.cpp:523
+    msdr_spectrum *S = new (std::nothrow) msdr_spectrum();
+    if (!S) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
+    S->ctx = ctx; S->channels = channels; S->spectrum_on = 1; S->counter = 0;
+    *out = S;
+    return 0;
+}
+extern "C" int msdr_spectrum_set_on(msdr_spectrum *S, int spectrum_on)
+{
+    if (!S) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    S->spectrum_on = spectrum_on ? 1 : 0;
+    return 0;
+}
+extern "C" int msdr_spectrum_show(msdr_spectrum *S, const q15_t *d_data, uint64_t channel_stride, q15_t *d_fft_out, uint8_t *d_columns, int *drawn)
+{
+    if (!S) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    if (drawn) *drawn = 0;
+    if (!S->spectrum_on) return 0;                                               // UI.cpp:533
+    if (--S->counter > 0) return 0;                                              // :534
+    S->counter = 25;                                                             // :535
+    if (int rc = msdr_rfft128_q15(S->ctx, d_data, channel_stride, d_fft_out, d_columns, S->channels)) return rc;
+    if (drawn) *drawn = 1;
+    return 0;
+}
+extern "C" int msdr_spectrum_destroy(msdr_spectrum *S)
+{
+    delete S;
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -130,5 +130,28 @@ void biquad_design(int kind, float frequency, float q_or_gain, float slope, doub
     }
 }
 
+// The three constant tables behind arm_rfft_q15 for 128 real points, regenerated from their documented formulas (the
+// reference ships them as literals): twiddleCoef_64_q15 = {cos, sin}(2 pi i / 64), i < 48, floor(x * 2^15) clipped to Q15
+// (arm_common_tables.c:12914); realCoefAQ15 / realCoefBQ15 = {0.5 (1 -/+ sin), -/+ 0.5 cos}(2 pi i / 128), i < 64,
+// round(x * 2^15) clipped (arm_rfft_init_q15.c:44-56, :1086-1098, read at twidCoefRModifier = 64, :2206).  Checked
+// entry by entry against the reference's literals (tests/golden: fft/*).
+void fft128_tables(int16_t tables[352])
+{
+    const double pi = 3.14159265358979323846;
+    auto q15 = [](double r) { return (int16_t)(r > 32767.0 ? 32767.0 : (r < -32768.0 ? -32768.0 : r)); };
+    for (int i = 0; i < 48; i++) {
+        tables[2 * i] = q15(floor(cos(2.0 * pi * i / 64.0) * 32768.0 + 1e-6));      // +1e-6: cos(pi/2) etc. are not exact zeros
+        tables[2 * i + 1] = q15(floor(sin(2.0 * pi * i / 64.0) * 32768.0 + 1e-6));
+    }
+    int16_t *a = tables + 96, *b = tables + 96 + 128;
+    for (int i = 0; i < 64; i++) {
+        const double sn = sin(2.0 * pi * i / 128.0), cs = cos(2.0 * pi * i / 128.0);
+        a[2 * i] = q15(floor(0.5 * (1.0 - sn) * 32768.0 + 0.5));
+        a[2 * i + 1] = q15(floor(-0.5 * cs * 32768.0 + 0.5));
+        b[2 * i] = q15(floor(0.5 * (1.0 + sn) * 32768.0 + 0.5));
+        b[2 * i + 1] = q15(floor(0.5 * cs * 32768.0 + 0.5));
+    }
+}
+
 }  // namespace design
 }  // namespace msdr

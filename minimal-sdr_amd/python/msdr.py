@@ -93,6 +93,14 @@ def load_library(path=None):
         _lib.msdr_syncam_get_state.argtypes = [_p, C.c_uint32, _p]
         _lib.msdr_syncam_constants.argtypes = [_p]
         _lib.msdr_syncam_constants.restype = None
+        _lib.msdr_rfft128_tables.argtypes = [_p]
+        _lib.msdr_rfft128_tables.restype = None
+        _lib.msdr_rfft_q15_init_check.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        _lib.msdr_rfft128_q15.argtypes = [_p, _p, C.c_uint64, _p, _p, C.c_uint32]
+        _lib.msdr_spectrum_create.argtypes = [_p, C.c_uint32, _p]
+        _lib.msdr_spectrum_set_on.argtypes = [_p, C.c_int]
+        _lib.msdr_spectrum_show.argtypes = [_p, _p, C.c_uint64, _p, _p, _p]
+        _lib.msdr_spectrum_destroy.argtypes = [_p]
     return _lib
 
 
@@ -118,6 +126,10 @@ def biquad_design(kind, freq, q_or_gain, slope=1.0, fs=AUDIO_SAMPLE_RATE_EXACT):
     return c
 
 
+class DeviceView:
+    ptr = None
+
+
 class DeviceArray:
     """A typed device buffer owned through msdr_malloc/msdr_free."""
 
@@ -138,6 +150,12 @@ class DeviceArray:
         out = np.empty(self.shape, self.dtype)
         _ck(self.ctx.lib.msdr_memcpy_d2h(self.ctx.h, _hp(out), self.ptr, self.nbytes))
         return out
+
+    def offset(self, nbytes):
+        """A non-owning view starting `nbytes` into this buffer (pointer arithmetic only)."""
+        v = DeviceView()
+        v.ptr = self.ptr + int(nbytes)
+        return v
 
     def fill(self, byte):
         _ck(self.ctx.lib.msdr_memset(self.ctx.h, self.ptr, int(byte), self.nbytes))
@@ -369,6 +387,44 @@ class Anr(_Instance):
 
 def dac_format_q15(ctx, d_src, d_dest, channels, n):
     _ck(ctx.lib.msdr_dac_format_q15(ctx.h, d_src.ptr if d_src is not None else None, d_dest.ptr, C.c_uint32(channels), C.c_uint32(n)))
+
+
+def rfft128_tables():
+    """(twiddleCoef_64_q15[96], realCoefAQ15[::64 pairs][128], realCoefBQ15[::64 pairs][128]) -- host side."""
+    t = np.zeros(352, np.int16)
+    load_library().msdr_rfft128_tables(_hp(t))
+    return t[:96], t[96:224], t[224:]
+
+
+def rfft128_q15(ctx, d_src, src_stride, nfft, d_fft_out=None, d_columns=None):
+    """arm_rfft_q15(&FFT(128, 0, 1), ...) batched (UI.cpp:551) + showSpectrum's column heights (UI.cpp:557-572)."""
+    _ck(ctx.lib.msdr_rfft128_q15(ctx.h, d_src.ptr, C.c_uint64(src_stride), d_fft_out.ptr if d_fft_out is not None else None,
+                                 d_columns.ptr if d_columns is not None else None, C.c_uint32(nfft)))
+
+
+class Spectrum:
+    """initSpectrum() / showSpectrum() (UI.cpp:520-592): Spectrum_on + the every-25th-call cadence."""
+
+    def __init__(self, ctx, channels):
+        self.ctx = ctx
+        h = _p()
+        _ck(ctx.lib.msdr_spectrum_create(ctx.h, C.c_uint32(channels), C.byref(h)))
+        self.h = h
+
+    def set_on(self, on):
+        _ck(self.ctx.lib.msdr_spectrum_set_on(self.h, int(on)))
+
+    def show(self, d_data, channel_stride, d_fft_out=None, d_columns=None):
+        drawn = C.c_int(0)
+        _ck(self.ctx.lib.msdr_spectrum_show(self.h, d_data.ptr, C.c_uint64(channel_stride),
+                                            d_fft_out.ptr if d_fft_out is not None else None,
+                                            d_columns.ptr if d_columns is not None else None, C.byref(drawn)))
+        return bool(drawn.value)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.msdr_spectrum_destroy(self.h)
+            self.h = None
 
 
 def syncam_constants():

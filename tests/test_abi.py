@@ -81,3 +81,21 @@ def test_no_cpu_fallback_without_gpu():
     assert "no CPU path" in str(e.value)
     assert lib.msdr_fir_q15_process(None, None, None, 128) != 0
     assert lib.msdr_chain_process(None, None, None, 128) != 0
+
+
+def test_rfft128_tables_match_reference_tables(golden):
+    """Row f4: the product regenerates the three CMSIS tables from their formulas; here they meet the reference's literals."""
+    tw, a, b = msdr.rfft128_tables()
+    assert np.array_equal(tw, golden["fft/twiddleCoef_64_q15"])
+    assert np.array_equal(a, golden["fft/realCoefAQ15_stride64"])
+    assert np.array_equal(b, golden["fft/realCoefBQ15_stride64"])
+
+
+def test_rfft_init_check_mirrors_arm_rfft_init_q15():
+    lib = msdr.load_library()
+    assert lib.msdr_rfft_q15_init_check(128, 0, 1) == 0
+    for n in (0, 16, 100, 129, 16384):                       # arm_rfft_init_q15.c:2217-2220
+        assert lib.msdr_rfft_q15_init_check(n, 0, 1) == msdr.STATUS_ARGUMENT_ERROR
+    for n in (32, 64, 256, 8192):                            # valid for CMSIS, not built here
+        assert lib.msdr_rfft_q15_init_check(n, 0, 1) == -2
+    assert lib.msdr_rfft_q15_init_check(128, 1, 1) == -2

@@ -1,0 +1,84 @@
+"""Row f4 (second half) on the GPU: the spectrum display's 128-point q15 real FFT + column heights (UI.cpp:520-592),
+through the C ABI, bit-exact against the oracle and against the reference-generated golden vectors."""
+import numpy as np
+import pytest
+
+from gpuhelp import ctx, msdr  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, x, stride=None):
+    """x: [nfft][128] int16 -> (fft_out [nfft][256], columns [nfft][127])"""
+    nfft = x.shape[0]
+    stride = stride or 128
+    buf = np.zeros((nfft, stride), np.int16)
+    buf[:, :128] = x
+    d = ctx.to_device(buf)
+    o, c = ctx.array((nfft, 256), np.int16), ctx.array((nfft, 128), np.uint8)
+    msdr.rfft128_q15(ctx, d, stride, nfft, o, c)
+    assert np.array_equal(d.download(), buf)             # the IF block is read-only here
+    col = c.download()
+    assert (col[:, 127] == 0).all()
+    return o.download(), col[:, :127]
+
+
+def test_rfft128_matches_golden(ctx, golden):
+    out, col = _run(ctx, golden["fft/x"])
+    assert np.array_equal(out, golden["fft/rfft128_out"])
+    want = np.minimum(np.abs(golden["fft/rfft128_out"][:, 127:0:-1].astype(np.int32)) // 200, 16)
+    assert np.array_equal(col, want)
+
+
+@pytest.mark.parametrize("nfft,stride", [(1, 128), (15, 128), (16, 128), (17, 136), (1000, 128), (4096, 256)])
+def test_rfft128_matches_oracle(ctx, orc, nfft, stride):
+    rng = np.random.default_rng(nfft)
+    amp = rng.choice([30, 3000, 32767], nfft)
+    x = (rng.integers(-32768, 32768, (nfft, 128)) * amp[:, None] // 32768).astype(np.int16)
+    x[::7, ::5] = -32768
+    x[3::11, 1::3] = 32767
+    out, col = _run(ctx, x, stride)
+    for f in range(nfft):
+        want, _ = orc.rfft128_q15(x[f])
+        assert np.array_equal(out[f], want), f
+        assert np.array_equal(col[f], orc.spectrum_columns(want)), f
+
+
+def test_rfft128_outputs_optional_and_argument_checks(ctx):
+    x = np.arange(256, dtype=np.int16).reshape(2, 128)
+    d = ctx.to_device(x)
+    o = ctx.array((2, 256), np.int16)
+    msdr.rfft128_q15(ctx, d, 128, 2, o, None)
+    c = ctx.array((2, 128), np.uint8)
+    msdr.rfft128_q15(ctx, d, 128, 2, None, c)
+    msdr.rfft128_q15(ctx, d, 128, 0, o, c)
+    with pytest.raises(msdr.MsdrError):
+        msdr.rfft128_q15(ctx, d, 100, 2, o, c)            # stride not a multiple of 8
+    with pytest.raises(msdr.MsdrError):
+        msdr.rfft128_q15(ctx, d, 64, 2, o, c)             # overlapping transforms
+
+
+def test_show_spectrum_cadence_over_block_stream(ctx, orc):
+    """showSpectrum(data) once per dequeued block (Minimal-SDR.ino:532): draws on the 1st call and then every 25th."""
+    ch, blocks = 6, 60
+    rng = np.random.default_rng(77)
+    x = rng.integers(-9000, 9001, (ch, blocks * 128)).astype(np.int16)
+    d = ctx.to_device(x)
+    sp = msdr.Spectrum(ctx, ch)
+    o, c = ctx.array((ch, 256), np.int16), ctx.array((ch, 128), np.uint8)
+    drawn = []
+    for b in range(blocks):
+        if b == 40:
+            sp.set_on(False)
+        if b == 45:
+            sp.set_on(True)
+        if sp.show(d.offset(b * 128 * 2), blocks * 128, o, c):
+            drawn.append(b)
+            out, col = o.download(), c.download()
+            for k in range(ch):
+                want, _ = orc.rfft128_q15(x[k, b * 128:(b + 1) * 128])
+                assert np.array_equal(out[k], want)
+                assert np.array_equal(col[k, :127], orc.spectrum_columns(want))
+    # counter: 0 -> draws at call 0, then 25; Spectrum_on == 0 skips the calls without counting (UI.cpp:533 returns first)
+    assert drawn == [0, 25, 55]
+    sp.close()

@@ -242,7 +242,7 @@ def bench_frontend(args, torch, msdr, dev, rank, local_rank, world, dist):
     dt = time.perf_counter() - t0
     if dist is not None:
         import msdr_dist
-        dt = msdr_dist.max_over_ranks(dt, dev)
+        dt = msdr_dist.max_over_ranks(dt, args.cdev)
     if rank != 0:
         return
     value = world * ch * n * args.steps / dt / 1e6
@@ -274,13 +274,79 @@ def bench_frontend(args, torch, msdr, dev, rank, local_rank, world, dist):
     print(json.dumps(out))
 
 
+def bench_spectrum(args, torch, msdr, dev, rank, local_rank, world, dist):
+    """Row f4: the display's 128-point q15 real FFT + column heights (UI.cpp:520-592) over every 128-sample block of a
+    4096-channel batch (the reference transforms one block in 25; here all of them, as a throughput figure)."""
+    ch, n = args.channels or 4096, args.samples or (1 << 15)
+    nfft = ch * (n // 128)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx = msdr.Context(local_rank, stream.cuda_stream)
+    g = torch.Generator(device=dev)
+    g.manual_seed(13 + rank)
+    x = torch.randint(-20000, 20001, (nfft, 128), device=dev, generator=g, dtype=torch.int32).to(torch.int16)
+    o = torch.empty((nfft, 256), dtype=torch.int16, device=dev)
+    c = torch.empty((nfft, 128), dtype=torch.uint8, device=dev)
+    lib = ctx.lib
+    import ctypes as C
+
+    def step():
+        rc = lib.msdr_rfft128_q15(ctx.h, C.c_void_p(x.data_ptr()), C.c_uint64(128), C.c_void_p(o.data_ptr()), C.c_void_p(c.data_ptr()),
+                                  C.c_uint32(nfft))
+        if rc != 0:
+            raise SystemExit("msdr_rfft128_q15: %s" % lib.msdr_last_error().decode())
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import msdr_dist
+        dt = msdr_dist.max_over_ranks(dt, args.cdev)
+    if rank != 0:
+        return
+    ms = dt / args.steps * 1e3
+    gbs = 896.0 * nfft / (ms * 1e-3) / 1e9
+    out = {"metric": "Msamples/s through the spectrum FFT (arm_rfft_q15 128 points + column heights); achieved HBM GB/s vs peak",
+           "value": round(world * nfft * 128 * args.steps / dt / 1e6, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "q15 (int16 in/out, 32-bit wrap-around products)", "data": "synthetic",
+           "config": {"workload": "spec: %d transforms of 128 samples (%d channels x %d blocks)" % (nfft, ch, n // 128),
+                      "kernel": "spectrum_rfft128_kernel"},
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "traffic": None, "note": "896 B per transform: 256 in + 512 FFT_out + 128 column bytes"}}
+    if not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orclib
+        orc = orclib.Oracle()
+        k = 4096
+        xs, og, cg = x[:k].cpu().numpy(), o[:k].cpu().numpy(), c[:k].cpu().numpy()
+        t1 = time.perf_counter()
+        bad = 0
+        for f in range(k):
+            want, _ = orc.rfft128_q15(xs[f])
+            bad += int((want != og[f]).sum()) + int((orc.spectrum_columns(want) != cg[f, :127]).sum())
+        cdt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(k * 128 / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                               "sample": "%d transforms of the same input through ctypes (oracle/msdr_oracle.c orc_rfft128_q15)" % k}
+        out["parity"] = {"mismatching_values": bad, "tolerance": 0}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "fe"],
-                    help="c2..c5 = BASELINE.json configs[1..4]; fe = the front end (SURVEY 8 f1) on the c3 shape")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "fe", "spec"],
+                    help="c2..c5 = BASELINE.json configs[1..4]; fe = the front end (SURVEY 8 f1) on the c3 shape; spec = the spectrum FFT (f4)")
     ap.add_argument("--samples", type=int, default=0, help="override samples per channel per step")
     ap.add_argument("--channels", type=int, default=0, help="override channels per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -305,16 +371,27 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the library has no CPU path")
+    # MSDR_BENCH_REHEARSAL=1: a dry run of the N>1 control flow on a ONE-GPU box -- every rank on device 0, gloo instead of
+    # RCCL (RCCL refuses two ranks on one device), collectives on host tensors.  Never a measurement; the line says so.
+    rehearsal = world > 1 and os.environ.get("MSDR_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    args.cdev = torch.device("cpu") if rehearsal else dev      # where the collectives' tensors live
 
     if args.workload == "fe":
         return bench_frontend(args, torch, msdr, dev, rank, local_rank, world, dist)
+    if args.workload == "spec":
+        return bench_spectrum(args, torch, msdr, dev, rank, local_rank, world, dist)
     wl = workload(args.workload, msdr, rank, args.osc_period)
     if args.samples:
         wl["n"] = args.samples
@@ -390,13 +467,13 @@ def main():
     chain.enable_timing(False)
     if dist is not None:
         import msdr_dist
-        dt = msdr_dist.max_over_ranks(dt, dev)
+        dt = msdr_dist.max_over_ranks(dt, args.cdev)
 
     gather = None
     if dist is not None:                                       # RCCL gather of demodulated audio, timed on its own
         rows = max(1, min(ch, (1 << 24) // n)) if n <= (1 << 24) else 1
         cols = min(n, 1 << 24)
-        part = y[:rows, :cols].contiguous()                    # a bounded slice of this rank's audio shard
+        part = y[:rows, :cols].contiguous().to(args.cdev)       # a bounded slice of this rank's audio shard
         full = msdr_dist.gather_audio(part, world * rows)
         barrier()
         g0 = time.perf_counter()
@@ -466,6 +543,8 @@ def main():
                 out["roofline"]["traffic_source"] = "profiles/r01/%s_rocprof_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % args.workload
     if gather:
         out["gather"] = gather
+    if os.environ.get("MSDR_BENCH_REHEARSAL", "0") == "1" and world > 1:
+        out["rehearsal"] = "all %d ranks shared ONE GPU, gloo collectives on host tensors: control-flow dry run, not a measurement" % world
     if not args.no_cpu and world == 1:
         x_host = x[:first_rows, :keep_x].cpu().numpy()
         cb, worst, per_row = cpu_baseline_q15(wl, x_host, gpu_first) if q15 else cpu_baseline(wl, x_host, gpu_first)

@@ -11,6 +11,7 @@
 #include "msdr_chain_mfw.hiph"
 #include "msdr_frontend.hiph"
 #include "msdr_spectrum.hiph"
+#include "msdr_chain_q15mf.hiph"
 #include "msdr_design.h"
 
 #include <algorithm>
@@ -998,6 +999,13 @@ struct msdr_chain {
     std::vector<DHist> dh_cache;                          // true numerator history per channel, valid while dh_gen == gen
     std::vector<uint64_t> dh_gen;
     uint64_t gen;                                         // process calls so far + 1
+    // Q15 matrix-core kernel (msdr_chain_q15mf.hiph): tables per (tap set, phase), channels ordered by tap set
+    char *d_qm_tab;
+    int qm_stride, qm_halo, qm_bsteps;
+    std::vector<char> qm_set_ok;      // per tap set: table built (every tap < 32640)
+    int *d_qm_order;                  // channels grouped by tap set
+    std::vector<uint32_t> qm_group_start, qm_group_count;
+    uint64_t qm_order_gen;
     msdr_biquad_q15 *nodes[2];
     msdr_syncam *pll;                 // Q15 + MSDR_CHAIN_SYNCAM_PLL: the PLL demodulator of SYNCAM channels and its Q scratch
     int16_t *d_pll_q;
@@ -1020,7 +1028,7 @@ static void chain_free(msdr_chain *c)
     hipFree(c->d_hist[0]); hipFree(c->d_hist[1]); hipFree(c->d_bq); hipFree(c->d_bq_state);
     hipFree(c->d_ftaps); hipFree(c->d_fset); hipFree(c->d_bq_fold);
     hipFree(c->d_fft_h); hipFree(c->d_fft_tw); hipFree(c->d_bq_fft); hipFree(c->d_mf_tab); hipFree(c->d_bq_mf); hipFree(c->d_bq_mf32);
-    hipFree(c->d_bq_state_alt); hipFree(c->d_units); hipFree(c->d_mw_iir);
+    hipFree(c->d_bq_state_alt); hipFree(c->d_units); hipFree(c->d_mw_iir); hipFree(c->d_qm_tab); hipFree(c->d_qm_order);
     for (int k = 0; k < 2; k++) if (c->nodes[k]) msdr_biquad_q15_destroy(c->nodes[k]);
     if (c->pll) msdr_syncam_destroy(c->pll);
     hipFree(c->d_pll_q);
@@ -1081,6 +1089,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->flags = cfg->flags; c->mfw_nw = 0; c->mfw_waves_per_cu = 0; c->d_bq_state_alt = nullptr; c->d_mw_iir = nullptr; c->d_units = nullptr; c->units_cap = 0;
     c->mode_gen = 1; c->units_mode_gen = 0; c->units_nseg = 0; c->units_wgs = 0; c->units_wgs_ssb = 0; c->mfw_ssb_fold = false; c->mfw_am_fold = false; c->units_tiles = -1;
     c->part_nseg[0] = c->part_nseg[1] = 1; c->part_seg_len[0] = c->part_seg_len[1] = 0;
+    c->d_qm_tab = nullptr; c->d_qm_order = nullptr; c->qm_stride = 0; c->qm_halo = 0; c->qm_bsteps = 0; c->qm_order_gen = 0;
     c->pll = nullptr; c->d_pll_q = nullptr; c->pll_q_cap = 0;
     c->anr = nullptr; c->d_anr_on = nullptr; c->anr_all = 0;
     if (f32) {
@@ -1153,6 +1162,66 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     }
     if (!rc) rc = dzalloc(ctx, (size_t)c->channels * c->hist_len, &c->d_hist[0]);
     if (!rc) rc = dzalloc(ctx, (size_t)c->channels * c->hist_len, &c->d_hist[1]);
+    // ---- Q15 on the integer matrix cores (msdr_chain_q15mf.hiph): byte-split Toeplitz fragments per (tap set, phase mod 4) ----
+    if (!rc && !f32 && cfg->mixer == MSDR_MIXER_FS4 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && qm_halo((int)c->ntaps) <= 512) {
+        const int N = (int)c->ntaps, H = qm_halo(N), NE = (H + 32) / 2, NC = (NE + 31) / 32;      // source-array elements / 32-element chunks
+        struct QTab { Q15MfHeader h; std::vector<int8_t> frags; };
+        std::vector<QTab> tabs((size_t)c->tapsets * 4);
+        c->qm_set_ok.assign(c->tapsets, 1);
+        int bsteps = 0;
+        for (uint32_t s = 0; s < c->tapsets; s++) {
+            const int16_t *cf[2] = {(const int16_t *)cfg->coeffs_i[s], (const int16_t *)cfg->coeffs_q[s]};
+            for (int o = 0; o < 2; o++)
+                for (int k = 0; k < N; k++) if (cf[o][k] >= 32640) c->qm_set_ok[s] = 0;          // ch = (c + 128) >> 8 would be 128
+            for (int rot = 0; rot < 4; rot++) {
+                QTab &T = tabs[(size_t)s * 4 + rot];
+                memset(&T.h, 0, sizeof T.h);
+                T.h.ok = c->qm_set_ok[s];
+                if (!T.h.ok) continue;
+                for (int o = 0; o < 2; o++) {
+                    // accumulator o (0 = I, 1 = Q) is fed by the window samples i whose mixer phase (rot + i) mod 4 is o or o + 2
+                    const int src = (o + 4 - rot) & 1;
+                    // B[e][b] = tap at delay H + b - (2 e + src) (CMSIS keeps the taps time-reversed: delay d is pCoeffs[N - 1 - d])
+                    auto Bv = [&](int e, int b) -> int { const int d = H + b - (2 * e + src); return (d >= 0 && d < N && e < NE) ? (int)cf[o][N - 1 - d] : 0; };
+                    int jlo = NC, jhi = -1;
+                    for (int j = 0; j < NC; j++) {
+                        bool any = false;
+                        for (int e = 32 * j; e < 32 * j + 32 && !any; e++)
+                            for (int b = 0; b < 32 && !any; b++) any = Bv(e, b) != 0;
+                        if (any) { jlo = std::min(jlo, j); jhi = std::max(jhi, j); }
+                    }
+                    T.h.src[o] = src; T.h.j0[o] = (jhi >= 0) ? jlo : 0; T.h.nsteps[o] = (jhi >= 0) ? jhi - jlo + 1 : 0;
+                    for (int par = 0; par < 2; par++) {
+                        unsigned sum = 0;
+                        for (int e = 0; e < NE; e++) sum += (unsigned)Bv(e, par);
+                        T.h.bias[o][par] = (int)(128u * sum);
+                    }
+                    for (int j = jlo; j <= jhi; j++) {
+                        const size_t base = T.frags.size();
+                        T.frags.resize(base + 2048);                                  // ch piece [64 lanes][16], then cl piece
+                        for (int l = 0; l < 64; l++)
+                            for (int jj = 0; jj < 16; jj++) {
+                                const int v = Bv(32 * j + 16 * (l >> 5) + jj, l & 31);
+                                const int lo = (int)(int8_t)(v & 0xFF), hi = (v - lo) >> 8;
+                                T.frags[base + l * 16 + jj] = (int8_t)hi;
+                                T.frags[base + 1024 + l * 16 + jj] = (int8_t)lo;
+                            }
+                    }
+                }
+                bsteps = std::max(bsteps, T.h.nsteps[0] + T.h.nsteps[1]);
+            }
+        }
+        if (bsteps > 0 && qm_lds_bytes(H, bsteps, 1) <= 160 * 1024) {
+            const int stride = kQmHdrBytes + bsteps * 2048;
+            std::vector<char> blob((size_t)stride * tabs.size(), 0);
+            for (size_t t = 0; t < tabs.size(); t++) {
+                memcpy(blob.data() + t * stride, &tabs[t].h, sizeof(Q15MfHeader));
+                if (!tabs[t].frags.empty()) memcpy(blob.data() + t * stride + kQmHdrBytes, tabs[t].frags.data(), tabs[t].frags.size());
+            }
+            rc = upload(ctx, blob, &c->d_qm_tab);
+            c->qm_stride = stride; c->qm_halo = H; c->qm_bsteps = bsteps;
+        }
+    }
     if (!rc && f32) {
         std::vector<BiquadCascadeTables<kChainR>> tabs(1);
         make_cascade_tables<kChainR>(cfg->biquad_coeffs, (int)c->nstages, &tabs[0]);
@@ -1624,6 +1693,9 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     }
     const bool use_mf = f32 && c->mf_ok;
     const bool use_mfw = use_mf && c->mfw_nw > 0 && !(c->flags & MSDR_CHAIN_MFMA_WG);
+    bool use_qm = !f32 && c->d_qm_tab != nullptr && !pll_active;
+    if (use_qm)
+        for (int ts : c->h_tapset) if (!c->qm_set_ok[ts]) { use_qm = false; break; }      // a tap >= 32640: the VALU kernel runs
     if (use_mf) use_fft = false;
     if (use_fft || use_mf) use_fold = false;
     const int kTile = use_mfw ? kMwTile : use_mf ? c->mf_waves * kMfWaveTile : use_fft ? kThreads * c->fft_LP : use_fold ? kFoldTile : kChainTile;
@@ -1787,6 +1859,56 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     else if (use_fold && c->fold_P == 2) { hipLaunchKernelGGL((chain_fold_kernel<2>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<2>"; }
     else if (use_fold) { hipLaunchKernelGGL((chain_fold_kernel<1>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<1>"; }
     else if (f32) hipLaunchKernelGGL((chain_kernel<ArithF32>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p);
+    else if (use_qm) {
+        // channels grouped by (tap set, flavour): a workgroup's waves share one table; one launch per group in use
+        const int env_flavour = (c->sqrt_kind == 1) ? 2 : 1;
+        auto flavour_of = [&](uint32_t ch) { const int m = c->h_mode[ch]; return (m == MSDR_MODE_LSB || m == MSDR_MODE_USB) ? 0 : env_flavour; };
+        if (c->qm_order_gen != c->mode_gen) {
+            std::vector<int> order;
+            c->qm_group_start.assign((size_t)c->tapsets * 3, 0); c->qm_group_count.assign((size_t)c->tapsets * 3, 0);
+            for (uint32_t s = 0; s < c->tapsets; s++)
+                for (int fl = 0; fl < 3; fl++) {
+                    const size_t gi = (size_t)s * 3 + fl;
+                    c->qm_group_start[gi] = (uint32_t)order.size();
+                    for (uint32_t ch = 0; ch < c->channels; ch++)
+                        if ((uint32_t)c->h_tapset[ch] == s && flavour_of(ch) == fl) order.push_back((int)ch);
+                    c->qm_group_count[gi] = (uint32_t)order.size() - c->qm_group_start[gi];
+                }
+            if (!c->d_qm_order) HIP_TRY(hipMalloc((void **)&c->d_qm_order, (size_t)c->channels * sizeof(int)));
+            HIP_TRY(hipMemcpyAsync(c->d_qm_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));
+            HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+            c->qm_order_gen = c->mode_gen;
+        }
+        const long long qtiles = ((long long)n_samples + kQmTile - 1) / kQmTile;
+        ChainParams q = p;
+        q.mf_tab = c->d_qm_tab; q.mf_stride = c->qm_stride; q.mf_halo = c->qm_halo; q.mf_bsteps = c->qm_bsteps; q.warm = 0; q.mf_units = c->d_qm_order;
+        int nw = 8;
+        long long qseg = 1;
+        for (size_t gi = 0; gi < c->qm_group_count.size(); gi++) {
+            const long long cnt = c->qm_group_count[gi];
+            if (!cnt) continue;
+            // every launch fills the GPU on its own: aim at two rounds of 16 waves per CU, at least two tiles per segment
+            qseg = (8192 + cnt - 1) / cnt;
+            qseg = std::max<long long>(1, std::min<long long>(qseg, std::max<long long>(1, qtiles / 2)));
+            if (c->time_segments > 0) qseg = std::max<long long>(1, std::min<long long>(c->time_segments, qtiles));
+            const long long qseg_len = ((qtiles + qseg - 1) / qseg) * kQmTile;
+            qseg = ((long long)n_samples + qseg_len - 1) / qseg_len;
+            nw = 8;
+            while (nw > 1 && cnt * qseg < 256LL * nw) nw >>= 1;
+            while (nw > 1 && qm_lds_bytes(c->qm_halo, c->qm_bsteps, nw) > 80 * 1024) nw >>= 1;     // two workgroups per CU
+            const size_t qlds = qm_lds_bytes(c->qm_halo, c->qm_bsteps, nw);
+            q.mf_nw = nw; q.nseg = (int)qseg; q.seg_len = qseg_len;
+            q.fold_period = (int)c->qm_group_start[gi]; q.fold_rot = (int)cnt; q.mf_waves = (int)(gi / 3);
+            grid = (unsigned)((cnt * qseg + nw - 1) / nw);
+            switch ((int)(gi % 3)) {
+            case 0: hipLaunchKernelGGL(chain_q15mf_kernel<0>, dim3(grid), dim3(nw * 64), qlds, c->ctx->stream, q); break;
+            case 1: hipLaunchKernelGGL(chain_q15mf_kernel<1>, dim3(grid), dim3(nw * 64), qlds, c->ctx->stream, q); break;
+            default: hipLaunchKernelGGL(chain_q15mf_kernel<2>, dim3(grid), dim3(nw * 64), qlds, c->ctx->stream, q); break;
+            }
+            if (int rc = launch_check("chain_q15mf_kernel")) return rc;
+        }
+        kname = "chain_q15mf_kernel"; block = (unsigned)nw * 64; nseg = qseg;
+    }
     else     hipLaunchKernelGGL((chain_kernel<ArithQ15>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p);
     if (int rc = launch_check("chain_kernel")) return rc;
     if (e0) { HIP_TRY(hipEventRecord(e1, c->ctx->stream)); c->events.emplace_back(e0, e1); }

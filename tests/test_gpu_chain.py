@@ -464,3 +464,95 @@ def test_chain_f32_mfw_repeatable_long_stream(ctx, orc):
         if first is None:
             first = got
         assert np.array_equal(got, first), rep          # bit-identical from launch to launch
+
+
+# ---------------------------------------------------------------- q15 on the integer matrix cores ----
+QM, VALU = "chain_q15mf_kernel", "chain_kernel<ArithQ15>"
+
+
+@pytest.mark.parametrize("mn,mode,ti,tq", CHAIN)
+@pytest.mark.parametrize("flags,kernel", [(0, QM), (msdr.CHAIN_NO_MFMA, VALU)])
+def test_chain_q15_both_kernels_match_reference_golden(ctx, golden, mn, mode, ti, tq, flags, kernel):
+    """The matrix-core kernel (default with the Fs/4 mixer) and the VALU kernel against the reference-generated vectors."""
+    sigs = ["am", "tones", "noise", "full"]
+    x = np.stack([golden["chain/x_" + s] for s in sigs])
+    for sk, suffix in ((msdr.SQRT_F32, ""), (msdr.SQRT_Q31, "_q31")):
+        if suffix and mn not in ("AM", "CW"):
+            continue
+        chain = msdr.Chain(ctx, msdr.ARITH_Q15, len(sigs), golden[ti], golden[tq], mode=mode, sqrt_kind=sk, flags=flags)
+        got = run_chain(ctx, chain, x, np.int16, 128)
+        assert chain.info()["kernel"] == kernel
+        for c, s in enumerate(sigs):
+            assert np.array_equal(got[c], golden["chain/%s_%s_audio%s" % (s, mn, suffix)]), (s, mn, kernel)
+
+
+@pytest.mark.parametrize("ntaps", [2, 30, 62, 100, 256, 512])
+def test_chain_q15_matrix_core_tap_counts_and_ragged_blocks(ctx, orc, ntaps):
+    """Any even tap count up to 512, blocks of ragged lengths (the mixer phase of a call's first sample cycles through
+    0..3, rows lose their 16-byte alignment, tiles are partial), full-scale input with -32768 runs."""
+    rng = np.random.default_rng(ntaps)
+    ch, n = 5, 19 * B
+    x = rng.integers(-32768, 32768, (ch, n)).astype(np.int16)
+    x[0, ::3] = -32768
+    x[1, :] = -32768
+    x[2, ::2] = 32767
+    ci = rng.integers(-3000, 3001, ntaps).astype(np.int16)
+    cq = rng.integers(-3000, 3001, ntaps).astype(np.int16)
+    modes = np.array([orclib.AM, orclib.LSB, orclib.USB, orclib.CW, orclib.SYNCAM], np.int32)
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, ci, cq, modes=modes)
+    got = np.empty_like(x)
+    o = 0
+    for m in [130, 7, 1025, 1, 2, 129, 3] + [n]:                 # the last entry takes the rest
+        m = min(m, n - o)
+        dx, dy = ctx.to_device(x[:, o:o + m]), ctx.array((ch, m), np.int16)
+        chain.process(dx, dy, m)
+        got[:, o:o + m] = dy.download()
+        assert chain.info()["kernel"] == QM
+        o += m
+        if o >= n:
+            break
+    for c in range(ch):
+        assert np.array_equal(got[c], orc.chain_q15(x[c], modes[c], ci, cq)), (ntaps, c)
+
+
+def test_chain_q15_matrix_core_accumulator_wraps_and_large_taps_fall_back(ctx, orc):
+    """arm_fir_fast_q15's 32-bit accumulator wraps (arm_fir_fast_q15.c:49-53): taps of 32639 x full-scale input force it.
+    A tap >= 32640 does not split into two signed bytes: that tap set runs on the VALU kernel -- same results."""
+    rng = np.random.default_rng(77)
+    x = rng.integers(-32768, 32768, (3, 12 * B)).astype(np.int16)
+    x[1] = np.where(np.arange(12 * B) % 4 < 2, 32767, -32768)     # after the Fs/4 signs every product has the same sign
+    for big, kernel in ((32639, QM), (32767, VALU), (-32768, QM)):
+        taps = np.full(64, big, np.int16)
+        for mode in (orclib.LSB, orclib.AM):
+            chain = msdr.Chain(ctx, msdr.ARITH_Q15, 3, taps, taps, mode=mode)
+            got = run_chain(ctx, chain, x, np.int16, None)
+            assert chain.info()["kernel"] == kernel
+            for c in range(3):
+                want, i_f, q_f = orc.chain_q15(x[c], mode, taps, taps, want_iq=True)
+                assert np.array_equal(got[c], want), (big, mode, c)
+            if big == 32639 and mode == orclib.LSB:
+                assert (np.abs(i_f.astype(np.int32)) == 32768).any() or (i_f == 32767).any()      # the FIR output saturates somewhere
+
+
+def test_chain_q15_matrix_core_time_segments_and_tapsets(ctx, orc, golden):
+    """Long blocks are cut into time segments (exact for a FIR: no state but the sample history); channels with different
+    tap sets and demodulators are separate launches."""
+    rng = np.random.default_rng(5)
+    ch, n = 7, 96 * B
+    x = rng.integers(-20000, 20001, (ch, n)).astype(np.int16)
+    sets_i = [golden["fir/taps_lp256"], np.concatenate([np.zeros(256 - 86, np.int16), golden["taps/FIR_SSB_I_coeffs"]])]
+    sets_q = [golden["fir/taps_lp256"], np.concatenate([np.zeros(256 - 86, np.int16), golden["taps/FIR_SSB_Q_coeffs"]])]
+    modes = np.array([orclib.AM, orclib.LSB, orclib.USB, orclib.AM, orclib.LSB, orclib.CW, orclib.USB], np.int32)
+    tapsets = np.array([0, 1, 1, 0, 1, 0, 1], np.int32)
+    for seg in (0, 3, 12):
+        chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, sets_i, sets_q, modes=modes, tapsets=tapsets, time_segments=seg)
+        got = run_chain(ctx, chain, x, np.int16, None)
+        info = chain.info()
+        assert info["kernel"] == QM
+        for c in range(ch):
+            assert np.array_equal(got[c], orc.chain_q15(x[c], modes[c], sets_i[tapsets[c]], sets_q[tapsets[c]])), (seg, c)
+    # a mode change regroups the channels
+    chain.set_mode(0, orclib.USB, 1)
+    got = run_chain(ctx, chain, x, np.int16, None)       # (the history carries over: compare the tail, past the FIR's memory)
+    want = orc.chain_q15(x[0], orclib.USB, sets_i[1], sets_q[1])
+    assert np.array_equal(got[0][512:], want[512:])

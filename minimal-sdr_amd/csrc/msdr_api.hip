@@ -1920,8 +1920,12 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         if (int rc = msdr_anr_q15(c->anr, c->d_anr_on, c->anr_all, (q15_t *)d_audio, (uint32_t)n_samples)) return rc;
 
     if (c->nnodes == 2) {      // biquad1_dac -> biquad2_dac in one pass over the audio
-        hipLaunchKernelGGL((biquad_teensy_kernel<2>), dim3((c->channels + 63) / 64), dim3(64), 0, c->ctx->stream, (short *)d_audio,
-                           c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);
+        if ((c->channels & 63u) == 0 && (n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 && !getenv("MSDR_NO_BIQUAD_PIPE"))
+            hipLaunchKernelGGL(biquad_teensy_pipe_kernel, dim3(c->channels / 64), dim3(128), 0, c->ctx->stream, (short *)d_audio,
+                               c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);     // node per wave, slab pipeline
+        else
+            hipLaunchKernelGGL((biquad_teensy_kernel<2>), dim3((c->channels + 63) / 64), dim3(64), 0, c->ctx->stream, (short *)d_audio,
+                               c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);
         if (int rc = launch_check("biquad_teensy_kernel<2>")) return rc;
     } else if (c->nnodes == 1) {
         if (int rc = msdr_biquad_q15_update(c->nodes[0], (q15_t *)d_audio, (uint32_t)n_samples)) return rc;

@@ -556,3 +556,24 @@ def test_chain_q15_matrix_core_time_segments_and_tapsets(ctx, orc, golden):
     got = run_chain(ctx, chain, x, np.int16, None)       # (the history carries over: compare the tail, past the FIR's memory)
     want = orc.chain_q15(x[0], orclib.USB, sets_i[1], sets_q[1])
     assert np.array_equal(got[0][512:], want[512:])
+
+
+@pytest.mark.parametrize("ch", [64, 192])
+def test_chain_q15_two_biquad_nodes_pipeline(ctx, orc, golden, ch):
+    """biquad1_dac -> biquad2_dac on whole 64-channel groups runs as a two-wave pipeline (one node per wave): multi-stage nodes,
+    state carried over calls, inputs that drive the Teensy biquad into saturation."""
+    rng = np.random.default_rng(ch)
+    n = 10 * B
+    x = rng.integers(-32768, 32768, (ch, n)).astype(np.int16)
+    x[1] = np.where((np.arange(n) // 40) % 2, 32767, -32768)                     # square wave at full scale
+    taps = golden["fir/taps_am102"]
+    corr = CORR
+    lr = [orc.biquad_design(orclib.BQ_LOWPASS, np.float32(5400 * corr), q) for q in (0.54, 1.3, 0.54, 1.3)]     # .ino:393-399
+    nt = orc.biquad_design(orclib.BQ_NOTCH, np.float32(3000 * corr), 15.0)
+    hs = orc.biquad_design(orclib.BQ_HIGHSHELF, np.float32(2000.0), 9.0, 0.8)
+    for nodes in ([lr, [nt]], [[nt], [hs, nt]]):
+        chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, taps, taps, mode=orclib.LSB, biquad_nodes=nodes)
+        got = run_chain(ctx, chain, x, np.int16, 2 * B)                           # five calls of two slabs each
+        for c in list(range(0, ch, 13)) + [1, ch - 1]:
+            want = orc.chain_q15(x[c], orclib.LSB, taps, taps, biquads=[orc.biquad_teensy_new(nd) for nd in nodes])
+            assert np.array_equal(got[c], want), (ch, c)

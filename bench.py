@@ -532,6 +532,16 @@ def main():
         r["mfma_f16_tflops_executed"] = round(mf * samples_per_step / (k_ms * 1e-3) / 1e12, 1)
         r["mfma_f16_frac"] = round(mf * samples_per_step / (k_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
         r["mfma_f16_peak_tflops"] = MFMA_F16_PEAK_TFLOPS
+    if info["kernel"].startswith("chain_q15mf"):
+        # integer matrix-core kernel: four v_mfma_i32_32x32x32_i8 (65536 integer ops each) per k-step and 1024-output wave tile
+        r = out["roofline"]
+        for k in ("valu_tflops_executed", "valu_frac_executed", "valu_peak_tflops"):
+            r.pop(k)
+        mi = 4 * 65536.0 * info["mfma_ksteps"] / 1024.0
+        r["mfma_i8_tops_executed"] = round(mi * samples_per_step / (k_ms * 1e-3) / 1e12, 1)
+        r["mfma_i8_frac"] = round(mi * samples_per_step / (k_ms * 1e-3) / 1e12 / (2 * MFMA_F16_PEAK_TFLOPS), 4)
+        r["mfma_i8_peak_tops"] = 2 * MFMA_F16_PEAK_TFLOPS
+        r["note"] = "kernel_ms / achieved are the FIR + demod kernel (4 B/sample); the step also runs the Teensy biquad nodes (serial per channel)"
     # HBM traffic per launch of the dominant kernel: the PMC passes cannot run inside this process (rocprofv3 wraps the command), so
     # the figure is the one tools/profile.sh measured for this workload and committed under profiles/ (FETCH_SIZE x 1024 x 2 +
     # WRITE_SIZE x 1024, corrected as MI355X_MICROARCH.md prescribes); null when no such profile is there or the shape was overridden

@@ -1942,7 +1942,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     c->info.grid = grid; c->info.block = block; c->info.lds_bytes = (uint32_t)lds;
     c->info.time_segments = (uint32_t)nseg; c->info.warmup = (uint32_t)p.warm; c->info.tile = (uint32_t)kTile;
     c->info.taps_padded = c->ntaps_pad;
-    c->info.mfma_ksteps = use_mf ? (uint32_t)c->mf_bsteps : 0u;
+    c->info.mfma_ksteps = use_mf ? (uint32_t)c->mf_bsteps : use_qm ? (uint32_t)c->qm_bsteps : 0u;
     return 0;
 }
 

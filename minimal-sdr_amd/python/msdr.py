@@ -139,6 +139,7 @@ class DeviceArray:
         ptr = _p()
         _ck(ctx.lib.msdr_malloc(ctx.h, self.nbytes, C.byref(ptr)))
         self.ptr = ptr.value
+        ctx._adopt(self)
 
     def upload(self, a):
         a = np.ascontiguousarray(a, self.dtype)
@@ -163,7 +164,8 @@ class DeviceArray:
 
     def free(self):
         if self.ptr:
-            self.ctx.lib.msdr_free(self.ctx.h, self.ptr)
+            if getattr(self.ctx, "h", None):
+                self.ctx.lib.msdr_free(self.ctx.h, self.ptr)
             self.ptr = None
 
     def __del__(self):
@@ -213,17 +215,37 @@ class Context:
                                     _p(d_i.ptr), _p(d_q.ptr), _p(d_out.ptr), C.c_uint32(channels), C.c_uint32(n)))
 
     def close(self):
+        """Destroys the context.  Objects created on it that are still alive are released first: a handle must never reach
+        the library after its context is gone (the garbage collector may run an object's __del__ long after the fixture that
+        owned the context has closed it)."""
         if self.h:
+            for obj in list(getattr(self, "_children", ())):
+                try:
+                    obj.close() if hasattr(obj, "close") else obj.free()
+                except Exception:
+                    pass
             self.lib.msdr_ctx_destroy(self.h)
             self.h = None
+
+    def _adopt(self, obj):
+        if not hasattr(self, "_children"):
+            import weakref
+            self._children = weakref.WeakSet()
+        self._children.add(obj)
 
 
 class _Instance:
     _destroy = None
 
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        if name == "ctx" and value is not None and hasattr(value, "_adopt"):
+            value._adopt(self)
+
     def close(self):
         if getattr(self, "h", None):
-            getattr(self.ctx.lib, self._destroy)(self.h)
+            if getattr(self.ctx, "h", None):            # context already destroyed: its objects went with it
+                getattr(self.ctx.lib, self._destroy)(self.h)
             self.h = None
 
     def __del__(self):
@@ -402,8 +424,9 @@ def rfft128_q15(ctx, d_src, src_stride, nfft, d_fft_out=None, d_columns=None):
                                  d_columns.ptr if d_columns is not None else None, C.c_uint32(nfft)))
 
 
-class Spectrum:
+class Spectrum(_Instance):
     """initSpectrum() / showSpectrum() (UI.cpp:520-592): Spectrum_on + the every-25th-call cadence."""
+    _destroy = "msdr_spectrum_destroy"
 
     def __init__(self, ctx, channels):
         self.ctx = ctx
@@ -420,11 +443,6 @@ class Spectrum:
                                             d_fft_out.ptr if d_fft_out is not None else None,
                                             d_columns.ptr if d_columns is not None else None, C.byref(drawn)))
         return bool(drawn.value)
-
-    def close(self):
-        if self.h:
-            self.ctx.lib.msdr_spectrum_destroy(self.h)
-            self.h = None
 
 
 def syncam_constants():

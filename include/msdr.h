@@ -307,7 +307,7 @@ typedef struct {
 } msdr_chain_config;
 #define MSDR_CHAIN_NO_TAP_FOLDING 1u /* F32: keep mixer and FIR pair as separate arithmetic steps (as written) */
 #define MSDR_CHAIN_NO_FFT 4u         /* F32: never use the overlap-save FFT kernel (long FIRs stay sliding dot products) */
-#define MSDR_CHAIN_NO_MFMA 8u        /* F32: never run the folded FIR on the matrix cores (split-fp16 MFMA kernel) */
+#define MSDR_CHAIN_NO_MFMA 8u        /* never run the FIR on the matrix cores (F32: split-fp16 MFMA kernel; Q15: byte-split i8 MFMA kernel) */
 #define MSDR_CHAIN_SYNCAM_PLL 32u    /* Q15: SYNCAM channels run the PLL demodulator (.ino:631-688) instead of the AM branch */
 #define MSDR_CHAIN_MFMA_WG 16u       /* F32: matrix-core kernel with workgroup tiles (msdr_chain_mfma.hiph) instead of one wave per stream */
 

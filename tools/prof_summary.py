@@ -19,16 +19,23 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
 line = [l for l in open(os.path.join(out, "trace.log")) if l.startswith("{")]
 if line:
     j = json.loads(line[-1])
-    print("\nbench line under the profiler: value %.1f %s, kernel_ms %.4f, achieved %.1f GB/s (frac %.4f)" % (
-        j["value"], j["unit"], j["roofline"]["kernel_ms"], j["roofline"]["achieved"], j["roofline"]["frac"]))
-    alg = 6.0 * j["config"]["channels_per_gpu"] * j["config"]["samples_per_channel_per_step"]
-    print("algorithmic bytes per launch: %.0f (2 B in + 4 B out per sample)" % alg)
+    print("\nbench line under the profiler: value %.1f %s, kernel_ms %s, achieved %.1f GB/s (frac %.4f)" % (
+        j["value"], j["unit"], j["roofline"].get("kernel_ms", j.get("ms_per_step")), j["roofline"]["achieved"], j["roofline"]["frac"]))
+    cfgj = j["config"]
+    if "channels_per_gpu" in cfgj:
+        q15 = cfgj.get("out") == "int16"
+        alg = (4.0 if q15 else 6.0) * cfgj["channels_per_gpu"] * cfgj["samples_per_channel_per_step"]
+        print("algorithmic bytes per launch: %.0f (2 B in + %d B out per sample)" % (alg, 2 if q15 else 4))
+    else:                       # spectrum workload: 896 B per transform
+        alg = 896.0 * int(cfgj["workload"].split()[1])
+        print("algorithmic bytes per launch: %.0f (896 B per transform)" % alg)
 res = {}
 for name in ("fetch", "write"):
     tot, cnt = 0.0, 0
     for f in glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "chain_" in r.get("Kernel_Name", "") and "kernel" in r.get("Kernel_Name", ""):
+            kn = r.get("Kernel_Name", "")
+            if ("chain_" in kn and "kernel" in kn) or "spectrum_rfft128" in kn:
                 tot += float(r.get("Counter_Value", 0)); cnt += 1
     res[name] = (tot, cnt)
     print("%s counter: %d chain_kernel dispatches, mean raw value %.1f" % (name.upper() + "_SIZE", cnt, tot / cnt if cnt else float("nan")))

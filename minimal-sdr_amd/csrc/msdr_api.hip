@@ -1163,7 +1163,24 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     if (!rc) rc = dzalloc(ctx, (size_t)c->channels * c->hist_len, &c->d_hist[0]);
     if (!rc) rc = dzalloc(ctx, (size_t)c->channels * c->hist_len, &c->d_hist[1]);
     // ---- Q15 on the integer matrix cores (msdr_chain_q15mf.hiph): byte-split Toeplitz fragments per (tap set, phase mod 4) ----
-    if (!rc && !f32 && cfg->mixer == MSDR_MIXER_FS4 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && qm_halo((int)c->ntaps) <= 512) {
+    // mixer: the Fs/4 loop, or a freq_conv table of period 4 that is zero in osc_q at one parity of phases and zero in osc_i at the
+    // other (the reference node driven at fs/4): then, too, every sample feeds only the I or only the Q filter
+    int qm_par[2] = {0, 1};                                   // phase parity that feeds the I / the Q accumulator
+    bool qm_mixer_ok = (cfg->mixer == MSDR_MIXER_FS4);
+    if (!f32 && cfg->mixer == MSDR_MIXER_NCO && cfg->osc_len % 4 == 0) {
+        const int16_t *oq = (const int16_t *)cfg->osc_q, *oi = (const int16_t *)cfg->osc_i;
+        bool ok = true;
+        for (uint32_t k = 4; k < cfg->osc_len && ok; k++) ok = (oq[k] == oq[k - 4]) && (oi[k] == oi[k - 4]);
+        int pq = -1, pi = -1;                                  // parity of the phases where osc_q / osc_i is not zero
+        for (int k = 0; k < 4 && ok; k++) {
+            if (oq[k] && oi[k]) ok = false;
+            if (oq[k]) { if (pq >= 0 && pq != (k & 1)) ok = false; pq = k & 1; }
+            if (oi[k]) { if (pi >= 0 && pi != (k & 1)) ok = false; pi = k & 1; }
+        }
+        if (ok && pq >= 0 && pi >= 0 && pq == pi) ok = false;
+        if (ok) { if (pq < 0) pq = (pi >= 0) ? 1 - pi : 0; if (pi < 0) pi = 1 - pq; qm_par[0] = pq; qm_par[1] = pi; qm_mixer_ok = true; }
+    }
+    if (!rc && !f32 && qm_mixer_ok && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && qm_halo((int)c->ntaps) <= 512) {
         const int N = (int)c->ntaps, H = qm_halo(N), NE = (H + 32) / 2, NC = (NE + 31) / 32;      // source-array elements / 32-element chunks
         struct QTab { Q15MfHeader h; std::vector<int8_t> frags; };
         std::vector<QTab> tabs((size_t)c->tapsets * 4);
@@ -1179,8 +1196,8 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                 T.h.ok = c->qm_set_ok[s];
                 if (!T.h.ok) continue;
                 for (int o = 0; o < 2; o++) {
-                    // accumulator o (0 = I, 1 = Q) is fed by the window samples i whose mixer phase (rot + i) mod 4 is o or o + 2
-                    const int src = (o + 4 - rot) & 1;
+                    // accumulator o (0 = I, 1 = Q) is fed by the window samples i whose mixer phase (rot + i) mod 4 has parity qm_par[o]
+                    const int src = (qm_par[o] + 4 - rot) & 1;
                     // B[e][b] = tap at delay H + b - (2 e + src) (CMSIS keeps the taps time-reversed: delay d is pCoeffs[N - 1 - d])
                     auto Bv = [&](int e, int b) -> int { const int d = H + b - (2 * e + src); return (d >= 0 && d < N && e < NE) ? (int)cf[o][N - 1 - d] : 0; };
                     int jlo = NC, jhi = -1;

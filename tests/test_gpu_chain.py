@@ -577,3 +577,43 @@ def test_chain_q15_two_biquad_nodes_pipeline(ctx, orc, golden, ch):
         for c in list(range(0, ch, 13)) + [1, ch - 1]:
             want = orc.chain_q15(x[c], orclib.LSB, taps, taps, biquads=[orc.biquad_teensy_new(nd) for nd in nodes])
             assert np.array_equal(got[c], want), (ch, c)
+
+
+@pytest.mark.parametrize("variant", ["fs4", "swapped", "minus32768", "gaps", "period8"])
+def test_chain_q15_nco_tables_on_matrix_cores(ctx, orc, golden, variant):
+    """AudioEffectFreqConv tables of period 4 with alternating zeros (the node driven at fs/4) run on the matrix-core kernel:
+    arm_mult_q15 (saturating) is applied when the samples are staged.  Other tables keep the VALU kernel.  Ragged blocks
+    advance the oscillator phase between calls."""
+    L = 128
+    k = np.arange(L)
+    c4 = {"fs4": ([32767, 0, -32767, 0], [0, 32767, 0, -32767]),
+          "swapped": ([0, 30000, 0, -30000], [-20000, 0, 20000, 0]),          # osc_q at the odd phases, osc_i at the even ones
+          "minus32768": ([-32768, 0, 32767, 0], [0, -32768, 0, -32768]),      # x = -32768 saturates in arm_mult_q15
+          "gaps": ([32767, 0, 0, 0], [0, 0, 0, -12345])}                        # phases that feed nothing
+    if variant == "period8":
+        oq = np.round(32767 * np.cos(2 * np.pi * k / 8)).astype(np.int16)
+        oi = np.round(32767 * np.sin(2 * np.pi * k / 8)).astype(np.int16)
+    else:
+        oq = np.array(c4[variant][0], np.int16)[k % 4]
+        oi = np.array(c4[variant][1], np.int16)[k % 4]
+    rng = np.random.default_rng(len(variant))
+    ch, n = 3, 24 * B
+    x = rng.integers(-32768, 32768, (ch, n)).astype(np.int16)
+    x[1, ::5] = -32768
+    hi, hq = golden["taps/FIR_SSB_I_coeffs"], golden["taps/FIR_SSB_Q_coeffs"]
+    modes = np.array([orclib.LSB, orclib.AM, orclib.USB], np.int32)
+    for flags in (0, msdr.CHAIN_NO_MFMA):
+        chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, hi, hq, mixer=msdr.MIXER_NCO, modes=modes, osc_i=oi, osc_q=oq, flags=flags)
+        got = np.empty_like(x)
+        o = 0
+        for m in [130, 7, 1025, 1, 2, 129, 3, n]:
+            m = min(m, n - o)
+            dx, dy = ctx.to_device(x[:, o:o + m]), ctx.array((ch, m), np.int16)
+            chain.process(dx, dy, m)
+            got[:, o:o + m] = dy.download()
+            o += m
+            if o >= n:
+                break
+        assert chain.info()["kernel"] == (QM if (flags == 0 and variant != "period8") else VALU)
+        for c in range(ch):
+            assert np.array_equal(got[c], orc.chain_q15(x[c], modes[c], hi, hq, mixer=1, osc_i=oi, osc_q=oq)), (variant, flags, c)

@@ -340,12 +340,92 @@ def bench_spectrum(args, torch, msdr, dev, rank, local_rank, world, dist):
     print(json.dumps(out))
 
 
+def bench_fir_stage(args, torch, msdr, dev, rank, local_rank, world, dist):
+    """The FIR STAGE on its own (rows A4 / A6): arm_fir_f32 (fp32 in / fp32 out, 8 B per sample) or, with --arith q15,
+    arm_fir_fast_q15 (int16 in / out, 4 B per sample), 256 taps, batched over 4096 channels x 2^18 samples."""
+    ch, n, nt = args.channels or 4096, args.samples or (1 << 18), args.taps or 256
+    q15 = args.arith == "q15"
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx = msdr.Context(local_rank, stream.cuda_stream)
+    g = torch.Generator(device=dev)
+    g.manual_seed(17 + rank)
+    lp = lowpass(nt)
+    if q15:
+        taps = np.round(lp.astype(np.float64) * 32767).astype(np.int16)
+        x = torch.randint(-8000, 8001, (ch, n), device=dev, generator=g, dtype=torch.int32).to(torch.int16)
+        y = torch.empty((ch, n), dtype=torch.int16, device=dev)
+        fir = msdr.FirQ15(ctx, taps, ch)
+        fn = ctx.lib.msdr_fir_q15_process
+    else:
+        taps = lp
+        x = (torch.rand((ch, n), device=dev, generator=g) * 16000.0 - 8000.0)
+        y = torch.empty((ch, n), dtype=torch.float32, device=dev)
+        fir = msdr.FirF32(ctx, taps, ch)
+        fn = ctx.lib.msdr_fir_f32_process
+    import ctypes as C
+
+    def step():
+        if fn(fir.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_uint32(n)) != 0:
+            raise SystemExit("fir process: %s" % ctx.lib.msdr_last_error().decode())
+    step()
+    torch.cuda.synchronize(dev)
+    first = y[:4, :1 << 14].cpu().numpy() if rank == 0 else None
+    for _ in range(max(0, args.warmup - 1)):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import msdr_dist
+        dt = msdr_dist.max_over_ranks(dt, args.cdev)
+    if rank != 0:
+        return
+    ms = dt / args.steps * 1e3
+    bps = 4.0 if q15 else 8.0
+    gbs = bps * ch * n / (ms * 1e-3) / 1e9
+    out = {"metric": "Msamples/s through the %d-tap FIR stage alone (%s); achieved HBM GB/s vs peak" % (nt, "arm_fir_fast_q15" if q15 else "arm_fir_f32"),
+           "value": round(world * ch * n * args.steps / dt / 1e6, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "q15" if q15 else "f32", "data": "synthetic",
+           "config": {"workload": "fir: %d channels x %d samples, %d taps, stage mirror msdr_fir_%s_process (includes its history kernel)" % (ch, n, nt, "q15" if q15 else "f32"),
+                      "kernel": "fir_kernel<%s>" % ("FirQ15" if q15 else "FirF32")},
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                        "note": "%d B per sample; 2 N flop per sample on the fp32 vector ALU (no matrix cores in the stage mirrors yet)" % int(bps)}}
+    if not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orclib
+        orc = orclib.Oracle()
+        xs = x[:4, :1 << 14].cpu().numpy()
+        t1 = time.perf_counter()
+        worst = 0.0
+        for c in range(xs.shape[0]):
+            if q15:
+                rc, want = orc.fir_q15_blocks(taps, xs[c], 128)
+                worst = max(worst, float((want != first[c]).sum()))
+            else:
+                want = orc.fir_f32_blocks(taps, xs[c], 128)
+                worst = max(worst, float(np.sqrt(((want.astype(np.float64) - first[c]) ** 2).sum() / max((want.astype(np.float64) ** 2).sum(), 1e-300))))
+        cdt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(xs.size / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                               "sample": "%d channels x %d samples of the same input (oracle/msdr_oracle.c)" % xs.shape}
+        out["parity"] = {("mismatching_samples" if q15 else "rel_rms_worst"): float("%.3g" % worst), "tolerance": 0 if q15 else 1e-6}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "fe", "spec"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "fe", "spec", "fir"],
                     help="c2..c5 = BASELINE.json configs[1..4]; fe = the front end (SURVEY 8 f1) on the c3 shape; spec = the spectrum FFT (f4)")
     ap.add_argument("--samples", type=int, default=0, help="override samples per channel per step")
     ap.add_argument("--channels", type=int, default=0, help="override channels per GPU")
@@ -392,6 +472,8 @@ def main():
         return bench_frontend(args, torch, msdr, dev, rank, local_rank, world, dist)
     if args.workload == "spec":
         return bench_spectrum(args, torch, msdr, dev, rank, local_rank, world, dist)
+    if args.workload == "fir":
+        return bench_fir_stage(args, torch, msdr, dev, rank, local_rank, world, dist)
     wl = workload(args.workload, msdr, rank, args.osc_period)
     if args.samples:
         wl["n"] = args.samples

@@ -292,6 +292,75 @@ static double max_pole_radius(const float *coeffs, int stages)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Q15 on the integer matrix cores (msdr_chain_q15mf.hiph): byte-split Toeplitz fragments per (tap set, phase mod 4).
+// par[o] = parity of the mixer phases that feed accumulator o (I, Q); fir_only: one filter over every sample (the FIR stage).
+// ------------------------------------------------------------------------------------------------
+struct QmTables { std::vector<char> blob; int stride = 0, halo = 0, bsteps = 0; std::vector<char> set_ok; };
+static void qm_build_tables(int N, uint32_t tapsets, const int16_t *const *coef_i, const int16_t *const *coef_q, const int par[2], bool fir_only, QmTables &out)
+{
+    const int H = qm_halo(N), NE = (H + 32) / 2, NC = (NE + 31) / 32;      // source-array elements / 32-element chunks
+    struct QTab { Q15MfHeader h; std::vector<int8_t> frags; };
+    std::vector<QTab> tabs((size_t)tapsets * 4);
+    out.set_ok.assign(tapsets, 1);
+    int bsteps = 0;
+    for (uint32_t s = 0; s < tapsets; s++) {
+        const int16_t *cf[2] = {coef_i[s], fir_only ? coef_i[s] : coef_q[s]};
+        for (int o = 0; o < (fir_only ? 1 : 2); o++)
+            for (int k = 0; k < N; k++) if (cf[o][k] >= 32640) out.set_ok[s] = 0;          // ch = (c - (int8)c) >> 8 would be 128
+        for (int rot = 0; rot < 4; rot++) {
+            QTab &T = tabs[(size_t)s * 4 + rot];
+            memset(&T.h, 0, sizeof T.h);
+            T.h.ok = out.set_ok[s];
+            if (!T.h.ok) continue;
+            int total = 0;
+            for (int o = 0; o < (fir_only ? 1 : 2); o++) {
+                unsigned bsum[2] = {0u, 0u};
+                for (int r = 0; r < (fir_only ? 2 : 1); r++) {
+                    // accumulator o is fed by the window samples i whose mixer phase (rot + i) mod 4 has parity par[o]; the FIR stage
+                    // takes both parities as two runs of the same accumulator
+                    const int src = fir_only ? r : ((par[o] + 4 - rot) & 1);
+                    // B[e][b] = tap at delay H + b - (2 e + src) (CMSIS keeps the taps time-reversed: delay d is pCoeffs[N - 1 - d])
+                    auto Bv = [&](int e, int b) -> int { const int d = H + b - (2 * e + src); return (d >= 0 && d < N && e < NE) ? (int)cf[o][N - 1 - d] : 0; };
+                    int jlo = NC, jhi = -1;
+                    for (int j = 0; j < NC; j++) {
+                        bool any = false;
+                        for (int e = 32 * j; e < 32 * j + 32 && !any; e++)
+                            for (int b = 0; b < 32 && !any; b++) any = Bv(e, b) != 0;
+                        if (any) { jlo = std::min(jlo, j); jhi = std::max(jhi, j); }
+                    }
+                    T.h.run[o][r].src = src; T.h.run[o][r].j0 = (jhi >= 0) ? jlo : 0; T.h.run[o][r].cnt = (jhi >= 0) ? jhi - jlo + 1 : 0;
+                    total += T.h.run[o][r].cnt;
+                    for (int pb = 0; pb < 2; pb++)
+                        for (int e = 0; e < NE; e++) bsum[pb] += (unsigned)Bv(e, pb);
+                    for (int j = jlo; j <= jhi; j++) {
+                        const size_t base = T.frags.size();
+                        T.frags.resize(base + 2048);                                  // ch piece [64 lanes][16], then cl piece
+                        for (int l = 0; l < 64; l++)
+                            for (int jj = 0; jj < 16; jj++) {
+                                const int v = Bv(32 * j + 16 * (l >> 5) + jj, l & 31);
+                                const int lo = (int)(int8_t)(v & 0xFF), hi = (v - lo) >> 8;
+                                T.frags[base + l * 16 + jj] = (int8_t)hi;
+                                T.frags[base + 1024 + l * 16 + jj] = (int8_t)lo;
+                            }
+                    }
+                }
+                T.h.bias[o][0] = (int)(128u * bsum[0]); T.h.bias[o][1] = (int)(128u * bsum[1]);
+            }
+            bsteps = std::max(bsteps, total);
+        }
+    }
+    if (bsteps > 0 && qm_lds_bytes(H, bsteps, 1) <= 160 * 1024) {
+        const int stride = kQmHdrBytes + bsteps * 2048;
+        out.blob.assign((size_t)stride * tabs.size(), 0);
+        for (size_t t = 0; t < tabs.size(); t++) {
+            memcpy(out.blob.data() + t * stride, &tabs[t].h, sizeof(Q15MfHeader));
+            if (!tabs[t].frags.empty()) memcpy(out.blob.data() + t * stride + kQmHdrBytes, tabs[t].frags.data(), tabs[t].frags.size());
+        }
+        out.stride = stride; out.halo = H; out.bsteps = bsteps;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // single-stream FIR instances (arm_fir_fast_q15 / arm_fir_f32 mirrors)
 // ------------------------------------------------------------------------------------------------
 template <typename In, typename El>
@@ -302,7 +371,12 @@ struct FirInst {
     In *d_hist[2];
     int cur;
 };
-struct msdr_fir_q15 : FirInst<int16_t, int32_t> {};
+struct msdr_fir_q15 : FirInst<int16_t, int32_t> {
+    // matrix-core path (chain_q15mf_kernel<3>): tables, channel list (identity), or null when a tap does not split into signed bytes
+    char *d_qm_tab = nullptr;
+    int *d_qm_order = nullptr;
+    int qm_stride = 0, qm_halo = 0, qm_bsteps = 0;
+};
 struct msdr_fir_f32 : FirInst<float, float> {};
 
 template <typename Inst, typename In, typename El>
@@ -384,14 +458,61 @@ extern "C" int msdr_fir_q15_create(msdr_ctx *ctx, uint16_t numTaps, const q15_t 
     if (out) *out = nullptr;
     if (numTaps & 1u)   // arm_fir_init_q15.c:93-96
         return fail(MSDR_STATUS_ARGUMENT_ERROR, "arm_fir_init_q15: numTaps must be even (got %u)", (unsigned)numTaps);
-    return fir_create<msdr_fir_q15, int16_t, int32_t>(ctx, numTaps, pCoeffs, channels, out);
+    if (int rc = fir_create<msdr_fir_q15, int16_t, int32_t>(ctx, numTaps, pCoeffs, channels, out)) return rc;
+    msdr_fir_q15 *S = *out;
+    if (qm_halo((int)numTaps) <= 512 && !getenv("MSDR_FIR_NO_MFMA")) {       // the same filter on the integer matrix cores (msdr_chain_q15mf.hiph)
+        const int16_t *ci[1] = {pCoeffs};
+        const int par[2] = {0, 1};
+        QmTables T;
+        qm_build_tables((int)numTaps, 1, ci, ci, par, true, T);
+        if (!T.blob.empty() && T.set_ok[0]) {
+            std::vector<int> order(channels);
+            for (uint32_t i = 0; i < channels; i++) order[i] = (int)i;
+            int rc = upload(ctx, T.blob, &S->d_qm_tab);
+            if (!rc) rc = upload(ctx, order, &S->d_qm_order);
+            if (rc) { msdr_fir_q15_destroy(S); *out = nullptr; return rc; }
+            S->qm_stride = T.stride; S->qm_halo = T.halo; S->qm_bsteps = T.bsteps;
+        }
+    }
+    return 0;
 }
 extern "C" int msdr_fir_q15_process(msdr_fir_q15 *S, const q15_t *d_src, q15_t *d_dst, uint32_t blockSize)
 {
-    return fir_process<FirQ15>(S, d_src, d_dst, blockSize);
+    if (!S || !S->d_qm_tab) return fir_process<FirQ15>(S, d_src, d_dst, blockSize);
+    if (int rc = bind(S->ctx)) return rc;
+    if (blockSize == 0) return 0;
+    if (!d_src || !d_dst) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    if ((const void *)d_src == (const void *)d_dst)
+        return fail(MSDR_STATUS_ARGUMENT_ERROR, "FIR process is not in-place (the reference uses separate buffers, Minimal-SDR.ino:574-578)");
+    ChainParams q;
+    memset(&q, 0, sizeof q);
+    q.x = d_src; q.out = d_dst; q.hist_in = S->d_hist[S->cur]; q.n = (long long)blockSize; q.channels = (int)S->channels;
+    q.hist_len = (int)S->hist_len; q.ntaps_pad = (int)S->ntaps_pad; q.mixer = MSDR_MIXER_FS4; q.phase0 = 0;
+    q.mf_tab = S->d_qm_tab; q.mf_stride = S->qm_stride; q.mf_halo = S->qm_halo; q.mf_bsteps = S->qm_bsteps; q.mf_units = S->d_qm_order;
+    const long long qtiles = ((long long)blockSize + kQmTile - 1) / kQmTile;
+    long long qseg = (8192 + S->channels - 1) / S->channels;                       // two rounds of 16 waves per CU, >= two tiles per segment
+    qseg = std::max<long long>(1, std::min<long long>(qseg, std::max<long long>(1, qtiles / 2)));
+    const long long qseg_len = ((qtiles + qseg - 1) / qseg) * kQmTile;
+    qseg = ((long long)blockSize + qseg_len - 1) / qseg_len;
+    int nw = 8;
+    while (nw > 1 && (long long)S->channels * qseg < 256LL * nw) nw >>= 1;
+    while (nw > 1 && qm_lds_bytes(S->qm_halo, S->qm_bsteps, nw) > 80 * 1024) nw >>= 1;
+    q.mf_nw = nw; q.nseg = (int)qseg; q.seg_len = qseg_len; q.fold_period = 0; q.fold_rot = (int)S->channels; q.mf_waves = 0;
+    const unsigned grid = (unsigned)(((long long)S->channels * qseg + nw - 1) / nw);
+    hipLaunchKernelGGL(chain_q15mf_kernel<3>, dim3(grid), dim3(nw * 64), qm_lds_bytes(S->qm_halo, S->qm_bsteps, nw), S->ctx->stream, q);
+    if (int rc = launch_check("chain_q15mf_kernel<3>")) return rc;
+    hipLaunchKernelGGL((history_kernel<int16_t>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
+                       d_src, (const int16_t *)S->d_hist[S->cur], S->d_hist[S->cur ^ 1], (long long)blockSize, (int)S->hist_len, (int)S->channels);
+    if (int rc = launch_check("history_kernel")) return rc;
+    S->cur ^= 1;
+    return 0;
 }
 extern "C" int msdr_fir_q15_reset(msdr_fir_q15 *S) { return fir_reset(S); }
-extern "C" int msdr_fir_q15_destroy(msdr_fir_q15 *S) { return fir_destroy(S); }
+extern "C" int msdr_fir_q15_destroy(msdr_fir_q15 *S)
+{
+    if (S) { hipFree(S->d_qm_tab); hipFree(S->d_qm_order); }
+    return fir_destroy(S);
+}
 
 extern "C" int msdr_fir_f32_create(msdr_ctx *ctx, uint16_t numTaps, const float32_t *pCoeffs, uint32_t channels, msdr_fir_f32 **out)
 {
@@ -1181,62 +1302,14 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         if (ok) { if (pq < 0) pq = (pi >= 0) ? 1 - pi : 0; if (pi < 0) pi = 1 - pq; qm_par[0] = pq; qm_par[1] = pi; qm_mixer_ok = true; }
     }
     if (!rc && !f32 && qm_mixer_ok && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && qm_halo((int)c->ntaps) <= 512) {
-        const int N = (int)c->ntaps, H = qm_halo(N), NE = (H + 32) / 2, NC = (NE + 31) / 32;      // source-array elements / 32-element chunks
-        struct QTab { Q15MfHeader h; std::vector<int8_t> frags; };
-        std::vector<QTab> tabs((size_t)c->tapsets * 4);
-        c->qm_set_ok.assign(c->tapsets, 1);
-        int bsteps = 0;
-        for (uint32_t s = 0; s < c->tapsets; s++) {
-            const int16_t *cf[2] = {(const int16_t *)cfg->coeffs_i[s], (const int16_t *)cfg->coeffs_q[s]};
-            for (int o = 0; o < 2; o++)
-                for (int k = 0; k < N; k++) if (cf[o][k] >= 32640) c->qm_set_ok[s] = 0;          // ch = (c + 128) >> 8 would be 128
-            for (int rot = 0; rot < 4; rot++) {
-                QTab &T = tabs[(size_t)s * 4 + rot];
-                memset(&T.h, 0, sizeof T.h);
-                T.h.ok = c->qm_set_ok[s];
-                if (!T.h.ok) continue;
-                for (int o = 0; o < 2; o++) {
-                    // accumulator o (0 = I, 1 = Q) is fed by the window samples i whose mixer phase (rot + i) mod 4 has parity qm_par[o]
-                    const int src = (qm_par[o] + 4 - rot) & 1;
-                    // B[e][b] = tap at delay H + b - (2 e + src) (CMSIS keeps the taps time-reversed: delay d is pCoeffs[N - 1 - d])
-                    auto Bv = [&](int e, int b) -> int { const int d = H + b - (2 * e + src); return (d >= 0 && d < N && e < NE) ? (int)cf[o][N - 1 - d] : 0; };
-                    int jlo = NC, jhi = -1;
-                    for (int j = 0; j < NC; j++) {
-                        bool any = false;
-                        for (int e = 32 * j; e < 32 * j + 32 && !any; e++)
-                            for (int b = 0; b < 32 && !any; b++) any = Bv(e, b) != 0;
-                        if (any) { jlo = std::min(jlo, j); jhi = std::max(jhi, j); }
-                    }
-                    T.h.src[o] = src; T.h.j0[o] = (jhi >= 0) ? jlo : 0; T.h.nsteps[o] = (jhi >= 0) ? jhi - jlo + 1 : 0;
-                    for (int par = 0; par < 2; par++) {
-                        unsigned sum = 0;
-                        for (int e = 0; e < NE; e++) sum += (unsigned)Bv(e, par);
-                        T.h.bias[o][par] = (int)(128u * sum);
-                    }
-                    for (int j = jlo; j <= jhi; j++) {
-                        const size_t base = T.frags.size();
-                        T.frags.resize(base + 2048);                                  // ch piece [64 lanes][16], then cl piece
-                        for (int l = 0; l < 64; l++)
-                            for (int jj = 0; jj < 16; jj++) {
-                                const int v = Bv(32 * j + 16 * (l >> 5) + jj, l & 31);
-                                const int lo = (int)(int8_t)(v & 0xFF), hi = (v - lo) >> 8;
-                                T.frags[base + l * 16 + jj] = (int8_t)hi;
-                                T.frags[base + 1024 + l * 16 + jj] = (int8_t)lo;
-                            }
-                    }
-                }
-                bsteps = std::max(bsteps, T.h.nsteps[0] + T.h.nsteps[1]);
-            }
-        }
-        if (bsteps > 0 && qm_lds_bytes(H, bsteps, 1) <= 160 * 1024) {
-            const int stride = kQmHdrBytes + bsteps * 2048;
-            std::vector<char> blob((size_t)stride * tabs.size(), 0);
-            for (size_t t = 0; t < tabs.size(); t++) {
-                memcpy(blob.data() + t * stride, &tabs[t].h, sizeof(Q15MfHeader));
-                if (!tabs[t].frags.empty()) memcpy(blob.data() + t * stride + kQmHdrBytes, tabs[t].frags.data(), tabs[t].frags.size());
-            }
-            rc = upload(ctx, blob, &c->d_qm_tab);
-            c->qm_stride = stride; c->qm_halo = H; c->qm_bsteps = bsteps;
+        std::vector<const int16_t *> ci(c->tapsets), cq(c->tapsets);
+        for (uint32_t s = 0; s < c->tapsets; s++) { ci[s] = (const int16_t *)cfg->coeffs_i[s]; cq[s] = (const int16_t *)cfg->coeffs_q[s]; }
+        QmTables T;
+        qm_build_tables((int)c->ntaps, c->tapsets, ci.data(), cq.data(), qm_par, false, T);
+        c->qm_set_ok = T.set_ok;
+        if (!T.blob.empty()) {
+            rc = upload(ctx, T.blob, &c->d_qm_tab);
+            c->qm_stride = T.stride; c->qm_halo = T.halo; c->qm_bsteps = T.bsteps;
         }
     }
     if (!rc && f32) {
@@ -1710,7 +1783,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     }
     const bool use_mf = f32 && c->mf_ok;
     const bool use_mfw = use_mf && c->mfw_nw > 0 && !(c->flags & MSDR_CHAIN_MFMA_WG);
-    bool use_qm = !f32 && c->d_qm_tab != nullptr && !pll_active;
+    bool use_qm = !f32 && c->d_qm_tab != nullptr;
     if (use_qm)
         for (int ts : c->h_tapset) if (!c->qm_set_ok[ts]) { use_qm = false; break; }      // a tap >= 32640: the VALU kernel runs
     if (use_mf) use_fft = false;

@@ -67,6 +67,7 @@ def test_syncam_in_the_q15_chain(ctx, orc):
         dx, dy = ctx.to_device(np.ascontiguousarray(x[:, b0:b0 + 5 * B])), ctx.array((ch, 5 * B), np.int16)
         chain.process(dx, dy, 5 * B)
         got[:, b0:b0 + 5 * B] = dy.download()
+    assert chain.info()["kernel"] == "chain_q15mf_kernel"     # the matrix-core kernel hands the PLL its I and Q
     for c in range(ch):
         if modes[c] == orclib.SYNCAM:
             _, i_f, q_f = orc.chain_q15(x[c], orclib.AM, taps, taps, want_iq=True)

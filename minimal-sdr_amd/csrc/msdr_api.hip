@@ -12,6 +12,7 @@
 #include "msdr_frontend.hiph"
 #include "msdr_spectrum.hiph"
 #include "msdr_chain_q15mf.hiph"
+#include "msdr_fir_f32mf.hiph"
 #include "msdr_design.h"
 
 #include <algorithm>
@@ -377,7 +378,12 @@ struct msdr_fir_q15 : FirInst<int16_t, int32_t> {
     int *d_qm_order = nullptr;
     int qm_stride = 0, qm_halo = 0, qm_bsteps = 0;
 };
-struct msdr_fir_f32 : FirInst<float, float> {};
+struct msdr_fir_f32 : FirInst<float, float> {
+    // matrix-core path (msdr_fir_f32mf.hiph): header + split-fp16 Toeplitz fragments, or null (then fir_kernel<FirF32> runs)
+    char *d_fm_tab = nullptr;
+    int fm_halo_ = 0, fm_bsteps = 0, fm_ex = 0;
+    float input_range = 32768.0f;
+};
 
 template <typename Inst, typename In, typename El>
 static int fir_create(msdr_ctx *ctx, uint16_t numTaps, const In *pCoeffs, uint32_t channels, Inst **out)
@@ -514,17 +520,91 @@ extern "C" int msdr_fir_q15_destroy(msdr_fir_q15 *S)
     return fir_destroy(S);
 }
 
+extern "C" int msdr_fir_f32_destroy(msdr_fir_f32 *S);
+static int fir_f32_upload_header(msdr_fir_f32 *S)
+{
+    int k = 0;
+    (void)std::frexp((double)S->input_range, &k);                 // input_range <= 2^k
+    if (std::ldexp(1.0, k - 1) == (double)S->input_range) k--;    // an exact power of two
+    F32MfHeader h;
+    h.nsteps = S->fm_bsteps; h.pre = (float)std::ldexp(1.0, 15 - k); h.post = (float)std::ldexp(1.0, k - 15 - S->fm_ex); h.pad = 0;
+    HIP_TRY(hipMemcpyAsync(S->d_fm_tab, &h, sizeof h, hipMemcpyHostToDevice, S->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(S->ctx->stream));
+    return 0;
+}
 extern "C" int msdr_fir_f32_create(msdr_ctx *ctx, uint16_t numTaps, const float32_t *pCoeffs, uint32_t channels, msdr_fir_f32 **out)
 {
     if (out) *out = nullptr;
-    return fir_create<msdr_fir_f32, float, float>(ctx, numTaps, pCoeffs, channels, out);
+    if (int rc = fir_create<msdr_fir_f32, float, float>(ctx, numTaps, pCoeffs, channels, out)) return rc;
+    msdr_fir_f32 *S = *out;
+    const int N = (int)numTaps, H = fm_halo(N), ns = (H + 32) / 16;
+    double maxabs = 0.0;
+    bool finite = true;
+    for (int k = 0; k < N; k++) { maxabs = std::max(maxabs, std::fabs((double)pCoeffs[k])); finite = finite && std::isfinite(pCoeffs[k]); }
+    if (N >= 16 && H <= 512 && finite && maxabs > 0.0 && !getenv("MSDR_FIR_NO_MFMA") && fm_lds_bytes(H, ns, 1) <= 160 * 1024) {
+        int ex = 0;
+        (void)std::frexp(maxabs, &ex);
+        ex = 14 - ex;                                             // maxabs 2^ex in [2^13, 2^14)
+        std::vector<char> blob(kFmHdrBytes + (size_t)ns * 2048, 0);
+        _Float16 *fr = reinterpret_cast<_Float16 *>(blob.data() + kFmHdrBytes);
+        for (int st = 0; st < ns; st++)
+            for (int l = 0; l < 64; l++)
+                for (int jj = 0; jj < 8; jj++) {
+                    // B[i][b] = tap at delay H + b - i (arm_fir keeps its coefficients time-reversed: delay d is pCoeffs[N - 1 - d])
+                    const int i = 16 * st + 8 * (l >> 5) + jj, b = l & 31, d = H + b - i;
+                    const double val = (d >= 0 && d < N) ? std::ldexp((double)pCoeffs[N - 1 - d], ex) : 0.0;
+                    const _Float16 vh = (_Float16)val;
+                    fr[(size_t)st * 1024 + l * 8 + jj] = vh;
+                    fr[(size_t)st * 1024 + 512 + l * 8 + jj] = (_Float16)(val - (double)vh);
+                }
+        int rc = upload(ctx, blob, &S->d_fm_tab);
+        S->fm_halo_ = H; S->fm_bsteps = ns; S->fm_ex = ex;
+        if (!rc) rc = fir_f32_upload_header(S);
+        if (rc) { msdr_fir_f32_destroy(S); *out = nullptr; return rc; }
+    }
+    return 0;
+}
+extern "C" int msdr_fir_f32_set_input_range(msdr_fir_f32 *S, float max_abs)
+{
+    if (!S) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
+    if (int rc = bind(S->ctx)) return rc;
+    if (!(max_abs > 0.0f) || !std::isfinite(max_abs)) return fail(MSDR_STATUS_ARGUMENT_ERROR, "input range must be positive and finite");
+    S->input_range = max_abs;
+    return S->d_fm_tab ? fir_f32_upload_header(S) : 0;
 }
 extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, float32_t *d_dst, uint32_t blockSize)
 {
-    return fir_process<FirF32>(S, d_src, d_dst, blockSize);
+    if (!S || !S->d_fm_tab) return fir_process<FirF32>(S, d_src, d_dst, blockSize);
+    if (int rc = bind(S->ctx)) return rc;
+    if (blockSize == 0) return 0;
+    if (!d_src || !d_dst) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    if ((const void *)d_src == (const void *)d_dst)
+        return fail(MSDR_STATUS_ARGUMENT_ERROR, "FIR process is not in-place (the reference uses separate buffers, Minimal-SDR.ino:574-578)");
+    const int H = S->fm_halo_, ns = S->fm_bsteps;
+    const long long tiles = ((long long)blockSize + kFmTile - 1) / kFmTile;
+    long long nseg = (8192 + S->channels - 1) / S->channels;                       // two rounds of 16 waves per CU, >= two tiles per segment
+    nseg = std::max<long long>(1, std::min<long long>(nseg, std::max<long long>(1, tiles / 2)));
+    const long long seg_len = ((tiles + nseg - 1) / nseg) * kFmTile;
+    nseg = ((long long)blockSize + seg_len - 1) / seg_len;
+    int nw = 16;
+    while (nw > 1 && ((long long)S->channels * nseg < 256LL * nw || fm_lds_bytes(H, ns, nw) > 160 * 1024)) nw >>= 1;
+    const unsigned grid = (unsigned)(((long long)S->channels * nseg + nw - 1) / nw);
+    hipLaunchKernelGGL(fir_f32mf_kernel, dim3(grid), dim3(nw * 64), fm_lds_bytes(H, ns, nw), S->ctx->stream, d_src, d_dst,
+                       (const float *)S->d_hist[S->cur], (const char *)S->d_fm_tab, (long long)blockSize, (int)S->channels, (int)nseg, seg_len,
+                       (int)S->hist_len, H, ns, nw);
+    if (int rc = launch_check("fir_f32mf_kernel")) return rc;
+    hipLaunchKernelGGL((history_kernel<float>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
+                       d_src, (const float *)S->d_hist[S->cur], S->d_hist[S->cur ^ 1], (long long)blockSize, (int)S->hist_len, (int)S->channels);
+    if (int rc = launch_check("history_kernel")) return rc;
+    S->cur ^= 1;
+    return 0;
 }
 extern "C" int msdr_fir_f32_reset(msdr_fir_f32 *S) { return fir_reset(S); }
-extern "C" int msdr_fir_f32_destroy(msdr_fir_f32 *S) { return fir_destroy(S); }
+extern "C" int msdr_fir_f32_destroy(msdr_fir_f32 *S)
+{
+    if (S) hipFree(S->d_fm_tab);
+    return fir_destroy(S);
+}
 
 // ------------------------------------------------------------------------------------------------
 // arm_biquad_cascade_df1_f32 mirror

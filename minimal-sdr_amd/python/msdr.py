@@ -93,6 +93,7 @@ def load_library(path=None):
         _lib.msdr_syncam_get_state.argtypes = [_p, C.c_uint32, _p]
         _lib.msdr_syncam_constants.argtypes = [_p]
         _lib.msdr_syncam_constants.restype = None
+        _lib.msdr_fir_f32_set_input_range.argtypes = [_p, C.c_float]
         _lib.msdr_rfft128_tables.argtypes = [_p]
         _lib.msdr_rfft128_tables.restype = None
         _lib.msdr_rfft_q15_init_check.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
@@ -289,6 +290,9 @@ class FirF32(_Instance):
 
     def reset(self):
         _ck(self.ctx.lib.msdr_fir_f32_reset(self.h))
+
+    def set_input_range(self, max_abs):
+        _ck(self.ctx.lib.msdr_fir_f32_set_input_range(self.h, C.c_float(max_abs)))
 
 
 class BiquadDf1F32(_Instance):

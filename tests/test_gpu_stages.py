@@ -211,3 +211,28 @@ def test_biquad_q15_bit_exact(ctx, orc, n_stage):
     with pytest.raises(msdr.MsdrError) as e:
         node.update(d, 7)
     assert e.value.status == msdr.STATUS_LENGTH_ERROR
+
+
+@pytest.mark.parametrize("scale,rng_hint", [(8000.0, None), (32767.0, None), (1.0, 1.0), (1e-3, 1e-3), (3.0e6, 4.0e6)])
+def test_fir_f32_matrix_core_input_ranges(ctx, orc, scale, rng_hint):
+    """arm_fir_f32 on the matrix cores: fp16 pieces after a power-of-two pre-scale taken from the declared input range
+    (default 32768).  Weak signals inside a strong range keep absolute accuracy; many channels and time segments."""
+    rng = np.random.default_rng(int(scale) + 5)
+    ch, n = 70, 9 * 1024 + 40
+    h = (np.sinc(0.23 * (np.arange(256) - 127.5)) * np.kaiser(256, 7.0)).astype(np.float32)
+    x = (rng.uniform(-1, 1, (ch, n)) * scale).astype(np.float32)
+    x[1] *= 1e-3                                                   # a weak channel next to full-scale ones
+    fir = msdr.FirF32(ctx, h, ch)
+    if rng_hint is not None:
+        fir.set_input_range(rng_hint)
+    got = np.empty_like(x)
+    for o, m in ((0, 5000), (5000, n - 5000)):
+        dx, dy = ctx.to_device(x[:, o:o + m]), ctx.array((ch, m), np.float32)
+        fir.process(dx, dy, m)
+        got[:, o:o + m] = dy.download()
+    for c in (0, 1, 2, 37, ch - 1):
+        want = orc.fir_f32_blocks(h, x[c, :(n // 128) * 128], 128)
+        err = rel_rms(got[c, :want.size], want)
+        assert err < (1e-6 if c != 1 else 2e-5), (scale, c, err)     # the weak channel: absolute accuracy relative to the range
+    truth = np.convolve(x[0].astype(np.float64), h.astype(np.float64))[:n]
+    assert rel_rms(got[0], truth) < 1e-6

@@ -396,9 +396,9 @@ def bench_fir_stage(args, torch, msdr, dev, rank, local_rank, world, dist):
            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "q15" if q15 else "f32", "data": "synthetic",
            "config": {"workload": "fir: %d channels x %d samples, %d taps, stage mirror msdr_fir_%s_process (includes its history kernel)" % (ch, n, nt, "q15" if q15 else "f32"),
-                      "kernel": "fir_kernel<%s>" % ("FirQ15" if q15 else "FirF32")},
+                      "kernel": "chain_q15mf_kernel<3> (i8 matrix cores)" if q15 else "fir_f32mf_kernel (split-fp16 matrix cores)"},
            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                        "note": "%d B per sample; 2 N flop per sample on the fp32 vector ALU (no matrix cores in the stage mirrors yet)" % int(bps)}}
+                        "note": "%d B per sample; matrix-core stage kernels (DESIGN.md 4.4)" % int(bps)}}
     if not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orclib

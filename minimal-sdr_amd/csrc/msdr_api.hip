@@ -588,6 +588,7 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
     nseg = ((long long)blockSize + seg_len - 1) / seg_len;
     int nw = 16;
     while (nw > 1 && ((long long)S->channels * nseg < 256LL * nw || fm_lds_bytes(H, ns, nw) > 160 * 1024)) nw >>= 1;
+    if (const char *e = getenv("MSDR_FM_NW")) nw = std::max(1, std::min(16, atoi(e)));           // experiment: waves per workgroup
     const unsigned grid = (unsigned)(((long long)S->channels * nseg + nw - 1) / nw);
     hipLaunchKernelGGL(fir_f32mf_kernel, dim3(grid), dim3(nw * 64), fm_lds_bytes(H, ns, nw), S->ctx->stream, d_src, d_dst,
                        (const float *)S->d_hist[S->cur], (const char *)S->d_fm_tab, (long long)blockSize, (int)S->channels, (int)nseg, seg_len,

@@ -236,3 +236,30 @@ def test_fir_f32_matrix_core_input_ranges(ctx, orc, scale, rng_hint):
         assert err < (1e-6 if c != 1 else 2e-5), (scale, c, err)     # the weak channel: absolute accuracy relative to the range
     truth = np.convolve(x[0].astype(np.float64), h.astype(np.float64))[:n]
     assert rel_rms(got[0], truth) < 1e-6
+
+
+@pytest.mark.parametrize("ntaps", [16, 100, 256, 512])
+def test_fir_q15_matrix_core_many_channels_and_segments(ctx, orc, golden, ntaps):
+    """arm_fir_fast_q15 batched on the integer matrix cores: many channels, ragged calls (unaligned rows, partial tiles, time
+    segments), full-scale input; bit-exact against the oracle (pinned to the compiled reference)."""
+    rng = np.random.default_rng(ntaps)
+    ch, n = 70, 9 * 1024 + 128
+    taps = rng.integers(-2500, 2501, ntaps).astype(np.int16)
+    taps[::7] = 32639                                             # the largest tap that still splits into two signed bytes
+    taps[3::11] = -32768
+    x = rng.integers(-32768, 32768, (ch, n)).astype(np.int16)
+    x[2] = -32768
+    fir = msdr.FirQ15(ctx, taps, ch)
+    got = np.empty_like(x)
+    o = 0
+    for m in (5000, 130, 7, n):
+        m = min(m, n - o)
+        dx, dy = ctx.to_device(np.ascontiguousarray(x[:, o:o + m])), ctx.array((ch, m), np.int16)
+        fir.process(dx, dy, m)
+        got[:, o:o + m] = dy.download()
+        o += m
+        if o >= n:
+            break
+    for c in (0, 1, 2, 37, ch - 1):
+        rc, want = orc.fir_q15_blocks(taps, x[c], 128)
+        assert rc == 0 and np.array_equal(got[c], want), (ntaps, c)

@@ -128,10 +128,10 @@ typedef struct msdr_fir_f32 msdr_fir_f32;
 int msdr_fir_f32_create(msdr_ctx *ctx, uint16_t numTaps, const float32_t *pCoeffs, uint32_t channels, msdr_fir_f32 **out);
 int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, float32_t *d_dst, uint32_t blockSize);
 int msdr_fir_f32_reset(msdr_fir_f32 *S);
-/* Filters of 16..513 taps run on the matrix cores with the samples split into two fp16 pieces (22 bits) after scaling by a power
- * of two taken from the expected input magnitude: default 32768 (int16-valued floats, as in the SDR chain); call this when the
- * data is scaled differently (e.g. 1.0 for normalised audio).  Samples above the range overflow; samples more than ~2^20 below it
- * lose relative accuracy.  No counterpart in CMSIS (arm_fir_f32 is plain fp32). */
+/* Filters of 16..513 taps run on the matrix cores with the samples as two fp16 pieces (22 bits) after a power-of-two scale.  By
+ * default the scale is chosen per 1024-sample tile from the data (block floating point): nothing to declare.  max_abs > 0 pins
+ * one scale for samples below that magnitude (saves the per-tile maximum; samples above it would overflow); 0 = automatic again.
+ * No counterpart in CMSIS (arm_fir_f32 is plain fp32). */
 int msdr_fir_f32_set_input_range(msdr_fir_f32 *S, float max_abs);
 int msdr_fir_f32_destroy(msdr_fir_f32 *S);
 

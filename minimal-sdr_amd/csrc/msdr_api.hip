@@ -382,7 +382,7 @@ struct msdr_fir_f32 : FirInst<float, float> {
     // matrix-core path (msdr_fir_f32mf.hiph): header + split-fp16 Toeplitz fragments, or null (then fir_kernel<FirF32> runs)
     char *d_fm_tab = nullptr;
     int fm_halo_ = 0, fm_bsteps = 0, fm_ex = 0;
-    float input_range = 32768.0f;
+    float input_range = 0.0f;            // 0 = block floating point per tile (default); > 0: a fixed scale for samples below this magnitude
 };
 
 template <typename Inst, typename In, typename El>
@@ -523,11 +523,14 @@ extern "C" int msdr_fir_q15_destroy(msdr_fir_q15 *S)
 extern "C" int msdr_fir_f32_destroy(msdr_fir_f32 *S);
 static int fir_f32_upload_header(msdr_fir_f32 *S)
 {
-    int k = 0;
-    (void)std::frexp((double)S->input_range, &k);                 // input_range <= 2^k
-    if (std::ldexp(1.0, k - 1) == (double)S->input_range) k--;    // an exact power of two
     F32MfHeader h;
-    h.nsteps = S->fm_bsteps; h.pre = (float)std::ldexp(1.0, 15 - k); h.post = (float)std::ldexp(1.0, k - 15 - S->fm_ex); h.pad = 0;
+    h.nsteps = S->fm_bsteps; h.ex = S->fm_ex; h.use_fixed = S->input_range > 0.0f ? 1 : 0; h.fixed_k = 0;
+    if (h.use_fixed) {
+        int k = 0;
+        (void)std::frexp((double)S->input_range, &k);                 // input_range <= 2^k
+        if (std::ldexp(1.0, k - 1) == (double)S->input_range) k--;    // an exact power of two
+        h.fixed_k = std::max(-100, std::min(100, 15 - k));
+    }
     HIP_TRY(hipMemcpyAsync(S->d_fm_tab, &h, sizeof h, hipMemcpyHostToDevice, S->ctx->stream));
     HIP_TRY(hipStreamSynchronize(S->ctx->stream));
     return 0;
@@ -568,7 +571,7 @@ extern "C" int msdr_fir_f32_set_input_range(msdr_fir_f32 *S, float max_abs)
 {
     if (!S) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
     if (int rc = bind(S->ctx)) return rc;
-    if (!(max_abs > 0.0f) || !std::isfinite(max_abs)) return fail(MSDR_STATUS_ARGUMENT_ERROR, "input range must be positive and finite");
+    if (!(max_abs >= 0.0f) || !std::isfinite(max_abs)) return fail(MSDR_STATUS_ARGUMENT_ERROR, "input range must be finite and >= 0 (0 = automatic)");
     S->input_range = max_abs;
     return S->d_fm_tab ? fir_f32_upload_header(S) : 0;
 }

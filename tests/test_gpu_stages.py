@@ -213,15 +213,19 @@ def test_biquad_q15_bit_exact(ctx, orc, n_stage):
     assert e.value.status == msdr.STATUS_LENGTH_ERROR
 
 
-@pytest.mark.parametrize("scale,rng_hint", [(8000.0, None), (32767.0, None), (1.0, 1.0), (1e-3, 1e-3), (3.0e6, 4.0e6)])
+@pytest.mark.parametrize("scale,rng_hint", [(8000.0, None), (32767.0, None), (1.0, None), (1e-3, None), (3.0e6, None), (1e-20, None), (1e30, None),
+                                            (1.0, 1.0), (3.0e6, 4.0e6)])
 def test_fir_f32_matrix_core_input_ranges(ctx, orc, scale, rng_hint):
-    """arm_fir_f32 on the matrix cores: fp16 pieces after a power-of-two pre-scale taken from the declared input range
-    (default 32768).  Weak signals inside a strong range keep absolute accuracy; many channels and time segments."""
-    rng = np.random.default_rng(int(scale) + 5)
+    """arm_fir_f32 on the matrix cores: fp16 pieces after a power-of-two scale chosen per tile from the data (block floating
+    point), whatever the caller's units; or pinned by msdr_fir_f32_set_input_range.  Many channels, two calls, time segments."""
+    rng = np.random.default_rng(int(min(scale, 1e6)) + 5)
     ch, n = 70, 9 * 1024 + 40
     h = (np.sinc(0.23 * (np.arange(256) - 127.5)) * np.kaiser(256, 7.0)).astype(np.float32)
     x = (rng.uniform(-1, 1, (ch, n)) * scale).astype(np.float32)
     x[1] *= 1e-3                                                   # a weak channel next to full-scale ones
+    x[2, 3000:] *= 1e-4                                            # level steps inside a channel: the scale follows tile by tile
+    x[2, 6000:] *= 1e6
+    x[3, 2000:2600] = 0.0
     fir = msdr.FirF32(ctx, h, ch)
     if rng_hint is not None:
         fir.set_input_range(rng_hint)
@@ -230,12 +234,19 @@ def test_fir_f32_matrix_core_input_ranges(ctx, orc, scale, rng_hint):
         dx, dy = ctx.to_device(x[:, o:o + m]), ctx.array((ch, m), np.float32)
         fir.process(dx, dy, m)
         got[:, o:o + m] = dy.download()
-    for c in (0, 1, 2, 37, ch - 1):
+    for c in (0, 1, 2, 3, 37, ch - 1):
+        if rng_hint is not None and c == 2:
+            continue                                               # the steps leave the declared range
         want = orc.fir_f32_blocks(h, x[c, :(n // 128) * 128], 128)
         err = rel_rms(got[c, :want.size], want)
-        assert err < (1e-6 if c != 1 else 2e-5), (scale, c, err)     # the weak channel: absolute accuracy relative to the range
+        assert err < (2e-5 if (rng_hint is not None and c == 1) else 1e-6), (scale, c, err)     # a pinned scale: absolute accuracy only
     truth = np.convolve(x[0].astype(np.float64), h.astype(np.float64))[:n]
     assert rel_rms(got[0], truth) < 1e-6
+    # level step: every stretch on its own (the quiet stretch must not be drowned by the loud one's rounding)
+    if rng_hint is None:
+        t2 = np.convolve(x[2].astype(np.float64), h.astype(np.float64))[:n]
+        for lo, hi, tol in ((400, 2900, 2e-6), (4200, 4900, 2e-6), (3600, 5900, 2e-5), (8200, n, 2e-6)):     # a tile next to a loud stretch carries the loud scale
+            assert rel_rms(got[2, lo:hi], t2[lo:hi]) < tol, (scale, lo)
 
 
 @pytest.mark.parametrize("ntaps", [16, 100, 256, 512])

@@ -618,6 +618,8 @@ struct msdr_biquad_df1_f32 {
     uint32_t channels, stages;
     BiquadCascadeTables<kBqR> *d_tabs;
     float *d_state;   // [channels][kBqStateFloats]
+    float *d_state_alt;   // ping-pong partner: a segmented launch reads one and writes the other
+    double pole_radius;
 };
 
 extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, const float32_t *pCoeffs, uint32_t channels,
@@ -630,12 +632,14 @@ extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, cons
     if ((numStages && !pCoeffs) || channels == 0) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad biquad arguments");
     msdr_biquad_df1_f32 *S = new (std::nothrow) msdr_biquad_df1_f32();
     if (!S) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
-    S->ctx = ctx; S->channels = channels; S->stages = numStages; S->d_tabs = nullptr; S->d_state = nullptr;
+    S->ctx = ctx; S->channels = channels; S->stages = numStages; S->d_tabs = nullptr; S->d_state = nullptr; S->d_state_alt = nullptr;
+    S->pole_radius = numStages ? max_pole_radius(pCoeffs, (int)numStages) : 0.0;
     std::vector<BiquadCascadeTables<kBqR>> tabs(1);
     make_cascade_tables<kBqR>(pCoeffs, numStages, &tabs[0]);
     int rc = upload(ctx, tabs, &S->d_tabs);
     if (!rc) rc = dzalloc(ctx, (size_t)channels * kBqStateFloats, &S->d_state);
-    if (rc) { hipFree(S->d_tabs); hipFree(S->d_state); delete S; return rc; }
+    if (!rc) rc = dzalloc(ctx, (size_t)channels * kBqStateFloats, &S->d_state_alt);
+    if (rc) { hipFree(S->d_tabs); hipFree(S->d_state); hipFree(S->d_state_alt); delete S; return rc; }
     *out = S;
     return 0;
 }
@@ -649,8 +653,23 @@ extern "C" int msdr_biquad_df1_f32_process(msdr_biquad_df1_f32 *S, const float32
         if (d_src != d_dst) HIP_TRY(hipMemcpyAsync(d_dst, d_src, (size_t)S->channels * blockSize * sizeof(float), hipMemcpyDeviceToDevice, S->ctx->stream));
         return 0;
     }
-    hipLaunchKernelGGL(biquad_df1_kernel, dim3(S->channels), dim3(kThreads), 0, S->ctx->stream, d_src, d_dst,
-                       (long long)blockSize, (const BiquadCascadeTables<kBqR> *)S->d_tabs, S->d_state);
+    // time segments for long blocks of few channels (never in place: a segment's warm-up reads its predecessor's input)
+    const long long tiles = ((long long)blockSize + kBqTile - 1) / kBqTile;
+    long long nseg = 1, warm_tiles = 0;
+    if ((const void *)d_src != (const void *)d_dst && S->pole_radius > 0.0 && S->pole_radius < 0.99999) {
+        const long long w = (long long)std::ceil(std::log(1e-10) / std::log(S->pole_radius)) + 64 * S->stages;
+        warm_tiles = (w + kBqTile - 1) / kBqTile;
+        if (warm_tiles <= 64) {
+            const long long want = (2048 + S->channels - 1) / S->channels;
+            nseg = std::max<long long>(1, std::min(want, tiles / std::max<long long>(4, 8 * warm_tiles)));
+        }
+    }
+    const long long seg_tiles = (tiles + nseg - 1) / nseg;
+    nseg = (tiles + seg_tiles - 1) / seg_tiles;
+    hipLaunchKernelGGL(biquad_df1_kernel, dim3((unsigned)(S->channels * nseg)), dim3(kThreads), 0, S->ctx->stream, d_src, d_dst,
+                       (long long)blockSize, (const BiquadCascadeTables<kBqR> *)S->d_tabs, (const float *)S->d_state, S->d_state_alt,
+                       (int)nseg, seg_tiles * kBqTile, (int)(nseg > 1 ? warm_tiles * kBqTile : 0));
+    std::swap(S->d_state, S->d_state_alt);
     return launch_check("biquad_df1_kernel");
 }
 extern "C" int msdr_biquad_df1_f32_reset(msdr_biquad_df1_f32 *S)
@@ -658,6 +677,7 @@ extern "C" int msdr_biquad_df1_f32_reset(msdr_biquad_df1_f32 *S)
     if (!S) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null instance");
     if (int rc = bind(S->ctx)) return rc;
     HIP_TRY(hipMemsetAsync(S->d_state, 0, (size_t)S->channels * kBqStateFloats * sizeof(float), S->ctx->stream));
+    HIP_TRY(hipMemsetAsync(S->d_state_alt, 0, (size_t)S->channels * kBqStateFloats * sizeof(float), S->ctx->stream));
     return 0;
 }
 extern "C" int msdr_biquad_df1_f32_destroy(msdr_biquad_df1_f32 *S)
@@ -665,7 +685,7 @@ extern "C" int msdr_biquad_df1_f32_destroy(msdr_biquad_df1_f32 *S)
     if (!S) return 0;
     if (int rc = bind(S->ctx)) return rc;
     (void)hipStreamSynchronize(S->ctx->stream);
-    hipFree(S->d_tabs); hipFree(S->d_state);
+    hipFree(S->d_tabs); hipFree(S->d_state); hipFree(S->d_state_alt);
     delete S;
     return 0;
 }

@@ -179,6 +179,34 @@ def test_biquad_df1_f32_vs_oracle(ctx, orc, stages):
         assert rel_rms(got[c], orc.biquad_df1_blocks(coeffs, x[c], 128)) < 2e-6
 
 
+def test_biquad_df1_f32_long_single_stream_is_segmented(ctx, orc):
+    """One channel x 2^21 samples: the stage cuts the block into time segments that re-converge over a warm-up (poles inside
+    the unit circle); two calls (state carried through the ping-pong record), and the in-place form (never segmented)."""
+    rng = np.random.default_rng(3)
+    corr = orclib.AUDIO_SAMPLE_RATE_EXACT / 24000.0
+    coeffs = []
+    for kind, f, q in ((orclib.BQ_LOWPASS, 5400 * corr, 0.54), (orclib.BQ_NOTCH, 3000 * corr, 15.0)):
+        c = orc.biquad_design(kind, np.float32(f), q).astype(np.float64) / 2 ** 30
+        coeffs.append([c[0], c[1], c[2], -c[3], -c[4]])
+    coeffs = np.array(coeffs, np.float32)
+    n = 1 << 21
+    x = rng.uniform(-1, 1, (1, n)).astype(np.float32)
+    want = orc.biquad_df1_blocks(coeffs, x[0], 128)
+    bq = msdr.BiquadDf1F32(ctx, coeffs, 1)
+    got = np.empty_like(x)
+    for o, m in ((0, n // 2 + 128), (n // 2 + 128, n // 2 - 128)):
+        dx, dy = ctx.to_device(x[:, o:o + m]), ctx.array((1, m), np.float32)
+        bq.process(dx, dy, m)
+        got[:, o:o + m] = dy.download()
+    assert rel_rms(got[0], want) < 2e-6
+    for lo in range(0, n, n // 64):                               # and locally, around would-be segment boundaries
+        assert rel_rms(got[0, lo:lo + 4096], want[lo:lo + 4096]) < 5e-6, lo
+    bq2 = msdr.BiquadDf1F32(ctx, coeffs, 1)
+    d = ctx.to_device(x)
+    bq2.process(d, d, n)                                          # in place
+    assert rel_rms(d.download()[0], want) < 2e-6
+
+
 # ---------------------------------------------------------------- A7 Teensy biquad ---------
 @pytest.mark.parametrize("n_stage", [1, 2, 4])
 def test_biquad_q15_bit_exact(ctx, orc, n_stage):

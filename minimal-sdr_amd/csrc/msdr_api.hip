@@ -329,7 +329,8 @@ static void qm_build_tables(int N, uint32_t tapsets, const int16_t *const *coef_
                             for (int b = 0; b < 32 && !any; b++) any = Bv(e, b) != 0;
                         if (any) { jlo = std::min(jlo, j); jhi = std::max(jhi, j); }
                     }
-                    T.h.run[o][r].src = src; T.h.run[o][r].j0 = (jhi >= 0) ? jlo : 0; T.h.run[o][r].cnt = (jhi >= 0) ? jhi - jlo + 1 : 0;
+                    if (jhi < 0) { jlo = 0; jhi = 0; }                                   // an all-zero filter: one chunk of zeros (the kernel's first k-step is unconditional)
+                    T.h.run[o][r].src = src; T.h.run[o][r].j0 = jlo; T.h.run[o][r].cnt = jhi - jlo + 1;
                     total += T.h.run[o][r].cnt;
                     for (int pb = 0; pb < 2; pb++)
                         for (int e = 0; e < NE; e++) bsum[pb] += (unsigned)Bv(e, pb);

@@ -26,6 +26,11 @@ if line:
         q15 = cfgj.get("out") == "int16"
         alg = (4.0 if q15 else 6.0) * cfgj["channels_per_gpu"] * cfgj["samples_per_channel_per_step"]
         print("algorithmic bytes per launch: %.0f (2 B in + %d B out per sample)" % (alg, 2 if q15 else 4))
+    elif cfgj["workload"].startswith("fir:"):     # FIR stage: "fir: C channels x N samples, ..."
+        w = cfgj["workload"].replace(",", " ").split()
+        bps = 4.0 if j.get("dtype") == "q15" else 8.0
+        alg = bps * int(w[1]) * int(w[4])
+        print("algorithmic bytes per launch: %.0f (%d B per sample)" % (alg, bps))
     else:                       # spectrum workload: 896 B per transform
         alg = 896.0 * int(cfgj["workload"].split()[1])
         print("algorithmic bytes per launch: %.0f (896 B per transform)" % alg)
@@ -35,7 +40,7 @@ for name in ("fetch", "write"):
     for f in glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             kn = r.get("Kernel_Name", "")
-            if ("chain_" in kn and "kernel" in kn) or "spectrum_rfft128" in kn:
+            if ("chain_" in kn and "kernel" in kn) or "spectrum_rfft128" in kn or "fir_f32mf" in kn:
                 tot += float(r.get("Counter_Value", 0)); cnt += 1
     res[name] = (tot, cnt)
     print("%s counter: %d chain_kernel dispatches, mean raw value %.1f" % (name.upper() + "_SIZE", cnt, tot / cnt if cnt else float("nan")))

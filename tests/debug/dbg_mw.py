@@ -1,7 +1,7 @@
 """Debug aid: error profile of the wave-stream matrix-core kernel against the oracle (run on the GPU box)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import orclib
 from gpuhelp import msdr

@@ -617,3 +617,30 @@ def test_chain_q15_nco_tables_on_matrix_cores(ctx, orc, golden, variant):
         assert chain.info()["kernel"] == (QM if (flags == 0 and variant != "period8") else VALU)
         for c in range(ch):
             assert np.array_equal(got[c], orc.chain_q15(x[c], modes[c], hi, hq, mixer=1, osc_i=oi, osc_q=oq)), (variant, flags, c)
+
+
+def test_chain_c1_shape_one_am_channel_block_cadence(ctx, orc, golden):
+    """BASELINE configs[0]: 1 AM channel, 128-sample AudioStream blocks, 61-tap low-pass (62 taps with the designer's zero pad),
+    envelope demodulator, 4-stage biquad (the Linkwitz-Riley set of Minimal-SDR.ino:393-399) -- block by block, both flavours."""
+    rng = np.random.default_rng(1)
+    nblk = 100
+    n = np.arange(nblk * B)
+    x = np.round(12000 * (0.5 + 0.4 * np.sin(2 * np.pi * 300 * n / 24000)) * np.cos(2 * np.pi * 6000 * n / 24000)) + rng.integers(-200, 201, n.size)
+    x = x.astype(np.int16)[None, :]
+    taps = golden["fir/taps_lp62"]
+    lr = [orc.biquad_design(orclib.BQ_LOWPASS, np.float32(5400 * CORR), q) for q in (0.54, 1.3, 0.54, 1.3)]
+    # Q15, as the reference runs it
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, 1, taps, taps, mode=orclib.AM, biquad_nodes=[lr])
+    got = run_chain(ctx, chain, x, np.int16, B)
+    want = orc.chain_q15(x[0], orclib.AM, taps, taps, biquads=[orc.biquad_teensy_new(lr)])
+    assert np.array_equal(got[0], want)
+    assert np.abs(want[20 * B:].astype(int)).max() > 1000                       # the envelope is there
+    # fp32 (arm_fir_f32 / arm_biquad_cascade_df1_f32 semantics), same taps and sections as floats
+    tf = (taps.astype(np.float64) / 32768.0).astype(np.float32)
+    bq = np.array([[c[0], c[1], c[2], -c[3], -c[4]] for c in (np.asarray(s, np.float64) / 2 ** 30 for s in lr)], np.float32)   # CMSIS adds the feedback terms
+    cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+    chain2 = msdr.Chain(ctx, msdr.ARITH_F32, 1, tf, tf, mode=orclib.AM, biquad_coeffs=bq)
+    got2 = run_chain(ctx, chain2, x, np.float32, B)
+    st = {}
+    want2 = np.concatenate([orc.chain_f32(x[0, b * B:(b + 1) * B], orclib.AM, tf, tf, sin4, cos4, bq, state=st) for b in range(nblk)])
+    assert rel_rms(got2[0], want2) < 1e-5

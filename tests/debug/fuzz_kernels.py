@@ -1,0 +1,137 @@
+"""Randomised differential test of the matrix-core kernels against the oracle (run from the repository root on a GPU box):
+    gpurun -- python tests/debug/fuzz_kernels.py [seconds] [seed]
+Q15 chain (random tap counts, tap sets, modes, mixers, call lengths, biquad nodes), arm_fir_fast_q15 stage, arm_fir_f32 stage."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from gpuhelp import msdr, rel_rms  # noqa: E402  (imports torch first)
+import orclib  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+orc = orclib.Oracle()
+ctx = msdr.Context(0)
+B = 128
+t_end = time.time() + budget
+cases = bad = 0
+
+
+def rand_x(ch, n):
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        return rng.integers(-32768, 32768, (ch, n)).astype(np.int16)
+    if kind == 1:
+        return rng.integers(-300, 301, (ch, n)).astype(np.int16)
+    if kind == 2:
+        x = rng.integers(-20000, 20001, (ch, n)).astype(np.int16)
+        x[:, ::int(rng.integers(2, 9))] = -32768
+        return x
+    return (np.sign(rng.standard_normal((ch, n))) * 32767).astype(np.int16)
+
+
+def splits(n):
+    out, o = [], 0
+    while o < n:
+        m = int(min(n - o, rng.choice([1, 2, 3, 7, 128, 130, 1000, 1024, 1025, 4096, 5000, n])))
+        out.append((o, m)); o += m
+    return out
+
+
+while time.time() < t_end:
+    which = rng.integers(0, 3)
+    cases += 1
+    if which == 0:      # Q15 chain
+        ntaps = int(rng.integers(1, 257)) * 2
+        nsets = int(rng.integers(1, 4))
+        ch = int(rng.choice([1, 3, 64, 70, 128]))
+        n = int(rng.integers(2, 60)) * B
+        amp = int(rng.choice([30, 3000, 32639]))
+        ci = [rng.integers(-amp, amp + 1, ntaps).astype(np.int16) for _ in range(nsets)]
+        cq = [rng.integers(-amp, amp + 1, ntaps).astype(np.int16) for _ in range(nsets)]
+        modes = rng.integers(0, 5, ch).astype(np.int32)
+        tapsets = rng.integers(0, nsets, ch).astype(np.int32)
+        mixer = int(rng.integers(0, 2))
+        oi = oq = None
+        if mixer:
+            a, b, c_, d = [int(v) for v in rng.integers(-32768, 32768, 4)]
+            pat = int(rng.integers(0, 2))
+            q4, i4 = ([a, 0, b, 0], [0, c_, 0, d]) if pat == 0 else ([0, a, 0, b], [c_, 0, d, 0])
+            oq, oi = np.array(q4, np.int16)[np.arange(B) % 4], np.array(i4, np.int16)[np.arange(B) % 4]
+        nodes = []
+        even_only = False
+        if rng.integers(0, 2):
+            lp = orc.biquad_design(orclib.BQ_LOWPASS, np.float32(rng.uniform(500, 9000)), float(rng.uniform(0.4, 3)))
+            nt = orc.biquad_design(orclib.BQ_NOTCH, np.float32(rng.uniform(500, 9000)), float(rng.uniform(1, 20)))
+            nodes = [[lp], [nt]][:int(rng.integers(1, 3))]
+            even_only = True
+        sk = int(rng.integers(0, 2))
+        x = rand_x(ch, n)
+        chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, ci, cq, mixer=mixer, modes=modes, tapsets=tapsets, osc_i=oi, osc_q=oq,
+                           biquad_nodes=nodes, sqrt_kind=sk)
+        got = np.empty_like(x)
+        # ragged calls; AudioFilterBiquad processes sample pairs, so with nodes every call length is made even
+        o = 0
+        for _, m in splits(n):
+            if o >= n:
+                break
+            m = min(m, n - o)
+            if even_only and (m & 1):
+                m = m + 1 if o + m + 1 <= n else m - 1
+            if m <= 0:
+                m = n - o
+            dx, dy = ctx.to_device(np.ascontiguousarray(x[:, o:o + m])), ctx.array((ch, m), np.int16)
+            chain.process(dx, dy, m)
+            got[:, o:o + m] = dy.download()
+            o += m
+        for c in rng.choice(ch, min(ch, 4), replace=False):
+            want = orc.chain_q15(x[c], modes[c], ci[tapsets[c]], cq[tapsets[c]], mixer=mixer, osc_i=oi, osc_q=oq, sqrt_kind=sk,
+                                 biquads=[orc.biquad_teensy_new(nd) for nd in nodes])
+            if not np.array_equal(got[c], want):
+                bad += 1
+                print("MISMATCH q15 chain", dict(seed=seed, case=cases, ntaps=ntaps, ch=ch, n=n, mixer=mixer, mode=int(modes[c]), nodes=len(nodes), sk=sk,
+                                                  kernel=chain.info()["kernel"], first=int(np.nonzero(got[c] != want)[0][0])))
+                break
+        chain.close()
+    elif which == 1:    # arm_fir_fast_q15 stage
+        ntaps = int(rng.integers(1, 257)) * 2
+        ch, n = int(rng.choice([1, 5, 70])), int(rng.integers(1, 80)) * B
+        taps = rng.integers(-int(rng.choice([50, 5000, 32639])), int(rng.choice([50, 5000, 32639])) + 1, ntaps).astype(np.int16)
+        x = rand_x(ch, n)
+        fir = msdr.FirQ15(ctx, taps, ch)
+        got = np.empty_like(x)
+        for o, m in splits(n):
+            dx, dy = ctx.to_device(np.ascontiguousarray(x[:, o:o + m])), ctx.array((ch, m), np.int16)
+            fir.process(dx, dy, m)
+            got[:, o:o + m] = dy.download()
+        c = int(rng.integers(0, ch))
+        rc, want = orc.fir_q15_blocks(taps, x[c], B)
+        if not np.array_equal(got[c], want):
+            bad += 1
+            print("MISMATCH fir q15", dict(seed=seed, case=cases, ntaps=ntaps, ch=ch, n=n))
+        fir.close()
+    else:               # arm_fir_f32 stage
+        ntaps = int(rng.integers(1, 513))
+        ch, n = int(rng.choice([1, 5, 70])), int(rng.integers(1, 80)) * B
+        h = (rng.standard_normal(ntaps) * 10.0 ** rng.uniform(-3, 1)).astype(np.float32)
+        x = (rng.standard_normal((ch, n)) * 10.0 ** rng.uniform(-6, 6)).astype(np.float32)
+        if rng.integers(0, 2):
+            x[:, n // 2:] *= np.float32(10.0 ** rng.uniform(-4, 4))
+        fir = msdr.FirF32(ctx, h, ch)
+        got = np.empty_like(x)
+        for o, m in splits(n):
+            dx, dy = ctx.to_device(np.ascontiguousarray(x[:, o:o + m])), ctx.array((ch, m), np.float32)
+            fir.process(dx, dy, m)
+            got[:, o:o + m] = dy.download()
+        c = int(rng.integers(0, ch))
+        want = np.convolve(x[c].astype(np.float64), h[::-1].astype(np.float64))[:n]     # pCoeffs are stored time-reversed
+        err = rel_rms(got[c], want)
+        if not err < 3e-6:
+            bad += 1
+            print("MISMATCH fir f32", dict(seed=seed, case=cases, ntaps=ntaps, ch=ch, n=n, err=err))
+        fir.close()
+    if cases % 50 == 0:
+        print("cases", cases, "bad", bad, flush=True)
+print("fuzz done: %d cases, %d mismatches (seed %d)" % (cases, bad, seed))
+sys.exit(1 if bad else 0)

@@ -292,6 +292,44 @@ static double max_pole_radius(const float *coeffs, int stages)
     return r;
 }
 
+// Conditioning of the "numerators first, all-pole sections afterwards" evaluation of a df1 cascade (msdr_biquad.hiph): kappa =
+// ||c||_1 ||g||_1 / ||h||_1 with c = product of the numerators, g = impulse response of the all-pole cascade, h = c * g the whole
+// filter's.  ~1 for low-pass sections; thousands when zeros and poles crowd the same spot (high-pass, narrow notches), and then the
+// parallel evaluation's error grows like kappa x 2.5e-8 on real signals (measured: LP + Q15 notch, kappa 19: 5e-7; one 300 Hz
+// high-pass section, kappa 300: 8e-6; two of them, kappa 1.7e5: 8e-3; tests/debug/iir_conditioning.py).  Above the limit the cascade runs
+// in CMSIS order (biquad_df1_seq_kernel).
+static double cascade_condition(const float *coeffs, int stages)
+{
+    if (stages <= 0) return 1.0;
+    std::vector<double> c(1, 1.0);
+    for (int s = 0; s < stages; s++) {
+        std::vector<double> nx(c.size() + 2, 0.0);
+        for (size_t i = 0; i < c.size(); i++)
+            for (int k = 0; k < 3; k++) nx[i + k] += c[i] * (double)coeffs[5 * s + k];
+        c.swap(nx);
+    }
+    const double r = max_pole_radius(coeffs, stages);
+    if (!(r < 0.99999)) return 1e30;
+    int len = r > 0 ? (int)std::min(200000.0, std::ceil(std::log(1e-12) / std::log(r)) + 64.0 * stages) : 16;
+    std::vector<double> g(len, 0.0);
+    g[0] = 1.0;
+    for (int s = 0; s < stages; s++) {                        // all-pole sections in series
+        const double a1 = coeffs[5 * s + 3], a2 = coeffs[5 * s + 4];
+        double y1 = 0, y2 = 0;
+        for (int k = 0; k < len; k++) { const double yv = g[k] + a1 * y1 + a2 * y2; y2 = y1; y1 = yv; g[k] = yv; }
+    }
+    double c1 = 0, g1 = 0, h1 = 0;
+    for (double v : c) c1 += std::fabs(v);
+    for (double v : g) g1 += std::fabs(v);
+    for (int k = 0; k < len; k++) {
+        double hv = 0;
+        for (size_t i = 0; i < c.size() && (int)i <= k; i++) hv += c[i] * g[k - i];
+        h1 += std::fabs(hv);
+    }
+    return h1 > 0 ? c1 * g1 / h1 : 1e30;
+}
+constexpr double kCascadeConditionLimit = 100.0;
+
 // ------------------------------------------------------------------------------------------------
 // Q15 on the integer matrix cores (msdr_chain_q15mf.hiph): byte-split Toeplitz fragments per (tap set, phase mod 4).
 // par[o] = parity of the mixer phases that feed accumulator o (I, Q); fir_only: one filter over every sample (the FIR stage).
@@ -621,6 +659,8 @@ struct msdr_biquad_df1_f32 {
     float *d_state;   // [channels][kBqStateFloats]
     float *d_state_alt;   // ping-pong partner: a segmented launch reads one and writes the other
     double pole_radius;
+    bool sequential;      // ill-conditioned for the parallel evaluation (cascade_condition): biquad_df1_seq_kernel, CMSIS order
+    float *d_coeffs;      // sequential: the 5 x stages coefficients
 };
 
 extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, const float32_t *pCoeffs, uint32_t channels,
@@ -635,6 +675,12 @@ extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, cons
     if (!S) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
     S->ctx = ctx; S->channels = channels; S->stages = numStages; S->d_tabs = nullptr; S->d_state = nullptr; S->d_state_alt = nullptr;
     S->pole_radius = numStages ? max_pole_radius(pCoeffs, (int)numStages) : 0.0;
+    S->d_coeffs = nullptr;
+    S->sequential = numStages > 0 && (cascade_condition(pCoeffs, (int)numStages) > kCascadeConditionLimit || getenv("MSDR_BIQUAD_SEQUENTIAL"));
+    if (S->sequential) {
+        std::vector<float> cf(pCoeffs, pCoeffs + 5 * numStages);
+        if (int rc = upload(ctx, cf, &S->d_coeffs)) { delete S; return rc; }
+    }
     std::vector<BiquadCascadeTables<kBqR>> tabs(1);
     make_cascade_tables<kBqR>(pCoeffs, numStages, &tabs[0]);
     int rc = upload(ctx, tabs, &S->d_tabs);
@@ -653,6 +699,11 @@ extern "C" int msdr_biquad_df1_f32_process(msdr_biquad_df1_f32 *S, const float32
     if (S->stages == 0) {      // empty cascade: pass-through
         if (d_src != d_dst) HIP_TRY(hipMemcpyAsync(d_dst, d_src, (size_t)S->channels * blockSize * sizeof(float), hipMemcpyDeviceToDevice, S->ctx->stream));
         return 0;
+    }
+    if (S->sequential) {
+        hipLaunchKernelGGL(biquad_df1_seq_kernel, dim3((S->channels + 63) / 64), dim3(64), 0, S->ctx->stream, d_src, d_dst, (long long)blockSize,
+                           (int)S->channels, (int)S->stages, (const float *)S->d_coeffs, S->d_state);
+        return launch_check("biquad_df1_seq_kernel");
     }
     // time segments for long blocks of few channels (never in place: a segment's warm-up reads its predecessor's input)
     const long long tiles = ((long long)blockSize + kBqTile - 1) / kBqTile;
@@ -686,7 +737,7 @@ extern "C" int msdr_biquad_df1_f32_destroy(msdr_biquad_df1_f32 *S)
     if (!S) return 0;
     if (int rc = bind(S->ctx)) return rc;
     (void)hipStreamSynchronize(S->ctx->stream);
-    hipFree(S->d_tabs); hipFree(S->d_state); hipFree(S->d_state_alt);
+    hipFree(S->d_tabs); hipFree(S->d_state); hipFree(S->d_state_alt); hipFree(S->d_coeffs);
     delete S;
     return 0;
 }
@@ -1232,6 +1283,7 @@ struct msdr_chain {
     int *d_qm_order;                  // channels grouped by tap set
     std::vector<uint32_t> qm_group_start, qm_group_count;
     uint64_t qm_order_gen;
+    msdr_biquad_df1_f32 *seq_bq;       // F32: the cascade is ill-conditioned for the parallel evaluation -> applied behind the main kernel in CMSIS order
     msdr_biquad_q15 *nodes[2];
     msdr_syncam *pll;                 // Q15 + MSDR_CHAIN_SYNCAM_PLL: the PLL demodulator of SYNCAM channels and its Q scratch
     int16_t *d_pll_q;
@@ -1256,6 +1308,7 @@ static void chain_free(msdr_chain *c)
     hipFree(c->d_fft_h); hipFree(c->d_fft_tw); hipFree(c->d_bq_fft); hipFree(c->d_mf_tab); hipFree(c->d_bq_mf); hipFree(c->d_bq_mf32);
     hipFree(c->d_bq_state_alt); hipFree(c->d_units); hipFree(c->d_mw_iir); hipFree(c->d_qm_tab); hipFree(c->d_qm_order);
     for (int k = 0; k < 2; k++) if (c->nodes[k]) msdr_biquad_q15_destroy(c->nodes[k]);
+    if (c->seq_bq) msdr_biquad_df1_f32_destroy(c->seq_bq);
     if (c->pll) msdr_syncam_destroy(c->pll);
     hipFree(c->d_pll_q);
     if (c->anr) msdr_anr_destroy(c->anr);
@@ -1290,8 +1343,22 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     auto mode_ok = [](int m) { return m >= MSDR_MODE_SYNCAM && m <= MSDR_MODE_CW; };
     if (!mode_ok(cfg->default_mode)) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad default_mode");
 
+    if (f32 && cfg->num_biquad_stages &&
+        (cascade_condition(cfg->biquad_coeffs, (int)cfg->num_biquad_stages) > kCascadeConditionLimit || getenv("MSDR_BIQUAD_SEQUENTIAL"))) {
+        // the parallel "numerators first" evaluation would lose accuracy on this cascade (cascade_condition): build the chain without
+        // it and run arm_biquad_cascade_df1_f32 as written behind the main kernel (one lane per channel)
+        msdr_chain_config plain = *cfg;
+        plain.num_biquad_stages = 0; plain.biquad_coeffs = nullptr;
+        if (int rc = msdr_chain_create(ctx, &plain, out)) return rc;
+        if (int rc = msdr_biquad_df1_f32_create(ctx, (uint8_t)cfg->num_biquad_stages, cfg->biquad_coeffs, cfg->channels, &(*out)->seq_bq)) {
+            msdr_chain_destroy(*out); *out = nullptr; return rc;
+        }
+        return 0;
+    }
+
     msdr_chain *c = new (std::nothrow) msdr_chain();
     if (!c) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
+    c->seq_bq = nullptr;
     c->ctx = ctx; c->arith = cfg->arith; c->mixer = cfg->mixer; c->sqrt_kind = cfg->sqrt_kind;
     c->channels = cfg->channels; c->ntaps = cfg->num_taps; c->ntaps_pad = (cfg->num_taps + 3u) & ~3u;
     c->hist_len = c->ntaps_pad - 1; c->tapsets = cfg->num_tapsets;
@@ -2108,6 +2175,9 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     if (int rc = launch_check("chain_kernel")) return rc;
     if (e0) { HIP_TRY(hipEventRecord(e1, c->ctx->stream)); c->events.emplace_back(e0, e1); }
 
+    if (c->seq_bq)             // F32, ill-conditioned cascade: arm_biquad_cascade_df1_f32 in CMSIS order, in place on the audio
+        if (int rc = msdr_biquad_df1_f32_process(c->seq_bq, (const float *)d_audio, (float *)d_audio, (uint32_t)n_samples)) return rc;
+
     if (pll_active)            // SYNCAM channels: I (in d_audio) and Q (scratch) -> PLL demodulator -> audio, before the biquad nodes
         if (int rc = msdr_syncam_q15(c->pll, c->d_mode, (const q15_t *)d_audio, c->d_pll_q, (q15_t *)d_audio, (uint32_t)n_samples)) return rc;
 
@@ -2133,7 +2203,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     c->cur ^= 1; c->gen++;
     c->phase = (c->phase + (long long)(n_samples % c->osc_len)) % c->osc_len;
 
-    snprintf(c->info.kernel, sizeof c->info.kernel, "%s", kname);
+    snprintf(c->info.kernel, sizeof c->info.kernel, "%s%s", kname, c->seq_bq ? " + biquad_df1_seq_kernel" : "");
     c->info.grid = grid; c->info.block = block; c->info.lds_bytes = (uint32_t)lds;
     c->info.time_segments = (uint32_t)nseg; c->info.warmup = (uint32_t)p.warm; c->info.tile = (uint32_t)kTile;
     c->info.taps_padded = c->ntaps_pad;
@@ -2153,6 +2223,7 @@ extern "C" int msdr_chain_reset(msdr_chain *c)
     // the reference never clears biquad history on retune (filter_biquad.cpp:95-97); init_FIR() only zeroes the FIR state.
     if (c->pll) if (int rc = msdr_syncam_reset(c->pll)) return rc;
     if (c->anr) if (int rc = msdr_anr_reset(c->anr)) return rc;
+    if (c->seq_bq) if (int rc = msdr_biquad_df1_f32_reset(c->seq_bq)) return rc;
     c->phase = 0; c->gen++;
     return 0;
 }

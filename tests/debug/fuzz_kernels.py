@@ -40,7 +40,7 @@ def splits(n):
 
 
 while time.time() < t_end:
-    which = rng.integers(0, 3)
+    which = rng.integers(0, 4)
     cases += 1
     if which == 0:      # Q15 chain
         ntaps = int(rng.integers(1, 257)) * 2
@@ -111,6 +111,54 @@ while time.time() < t_end:
             bad += 1
             print("MISMATCH fir q15", dict(seed=seed, case=cases, ntaps=ntaps, ch=ch, n=n))
         fir.close()
+    elif which == 3:    # fp32 chain (matrix-core kernels for period-1/2/4 oscillators, else the general kernel)
+        ntaps = int(rng.integers(2, 300))
+        ch = int(rng.choice([1, 3, 40]))
+        n = int(rng.integers(2, 80)) * B
+        hi = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+        hq = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+        modes = rng.choice([orclib.AM, orclib.LSB, orclib.USB, orclib.CW], ch).astype(np.int32)
+        if (modes == orclib.AM).any() or (modes == orclib.CW).any():
+            hq = hi.copy() if rng.integers(0, 2) else hq
+        mixer = int(rng.integers(0, 2))
+        P = int(rng.choice([1, 2, 4, 8]))
+        k = np.arange(B)
+        if mixer:
+            oi = (np.round(32767 * np.sin(2 * np.pi * k / P)).astype(np.int16) / 32768.0).astype(np.float32)
+            oq = (np.round(32767 * np.cos(2 * np.pi * k / P)).astype(np.int16) / 32768.0).astype(np.float32)
+        else:
+            oi, oq = np.array([0, 1, 0, -1], np.float32)[k % 4], np.array([1, 0, -1, 0], np.float32)[k % 4]
+        stages = int(rng.integers(0, 5))
+        bq = None
+        if stages:
+            rows = []
+            for _ in range(stages):
+                kind = int(rng.choice([orclib.BQ_LOWPASS, orclib.BQ_NOTCH, orclib.BQ_HIGHPASS]))
+                c_ = orc.biquad_design(kind, np.float32(rng.uniform(800, 9000)), float(rng.uniform(0.5, 8))).astype(np.float64) / 2 ** 30
+                rows.append([c_[0], c_[1], c_[2], -c_[3], -c_[4]])
+            bq = np.array(rows, np.float32)
+        x = rand_x(ch, n)
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, hi, hq, mixer=mixer, modes=modes, osc_i=oi if mixer else None, osc_q=oq if mixer else None,
+                           biquad_coeffs=bq, time_segments=int(rng.choice([0, 0, 1, 3])))
+        got = np.empty((ch, n), np.float32)
+        o = 0
+        for _, m in splits(n):
+            if o >= n:
+                break
+            m = min(m, n - o)
+            dx, dy = ctx.to_device(np.ascontiguousarray(x[:, o:o + m])), ctx.array((ch, m), np.float32)
+            chain.process(dx, dy, m)
+            got[:, o:o + m] = dy.download()
+            o += m
+        for c in rng.choice(ch, min(ch, 3), replace=False):
+            want = orc.chain_f32(x[c], modes[c], hi, hq, oi, oq, bq)
+            err = rel_rms(got[c], want)
+            if not err < 1e-5:
+                bad += 1
+                print("MISMATCH f32 chain", dict(seed=seed, case=cases, ntaps=ntaps, ch=ch, n=n, mixer=mixer, P=P, mode=int(modes[c]), stages=stages, err=err,
+                                                  kernel=chain.info()["kernel"]))
+                break
+        chain.close()
     else:               # arm_fir_f32 stage
         ntaps = int(rng.integers(1, 513))
         ch, n = int(rng.choice([1, 5, 70])), int(rng.integers(1, 80)) * B

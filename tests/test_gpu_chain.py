@@ -644,3 +644,33 @@ def test_chain_c1_shape_one_am_channel_block_cadence(ctx, orc, golden):
     st = {}
     want2 = np.concatenate([orc.chain_f32(x[0, b * B:(b + 1) * B], orclib.AM, tf, tf, sin4, cos4, bq, state=st) for b in range(nblk)])
     assert rel_rms(got2[0], want2) < 1e-5
+
+
+@pytest.mark.parametrize("mode", [orclib.AM, orclib.LSB])
+@pytest.mark.parametrize("spec", [[(1, 300, 0.7), (1, 300, 0.7)], [(1, 300, 0.7)], [(3, 1000, 8), (3, 2000, 8), (3, 3000, 8), (3, 4000, 8)]])
+def test_chain_f32_ill_conditioned_cascade_runs_in_cmsis_order(ctx, orc, mode, spec):
+    """Stacked high-pass / narrow-notch sections behind an envelope: the chain measures the cascade's conditioning and applies
+    arm_biquad_cascade_df1_f32 as written behind the main kernel (the parallel evaluation measured 8e-3 on the first case)."""
+    rng = np.random.default_rng(17)
+    k = np.arange(100)
+    proto = np.sinc(1920 / 24000 * (k - 49.5)) * np.kaiser(100, 6.0)
+    proto /= proto.sum()
+    hi = (2 * proto * np.cos(2 * np.pi * 1330 / 24000 * (k - 49.5) + np.pi / 4)).astype(np.float32)
+    hq = (2 * proto * np.cos(2 * np.pi * 1330 / 24000 * (k - 49.5) - np.pi / 4)).astype(np.float32)
+    cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+    rows = []
+    for kind, f, q in spec:
+        c_ = orc.biquad_design(kind, np.float32(f * CORR), q).astype(np.float64) / 2 ** 30
+        rows.append([c_[0], c_[1], c_[2], -c_[3], -c_[4]])
+    bq = np.array(rows, np.float32)
+    ch, n = 5, 40 * B
+    x = rng.integers(-12000, 12001, (ch, n)).astype(np.int16)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, hi, hq, mode=mode, biquad_coeffs=bq)
+    got = run_chain(ctx, chain, x, np.float32, 13 * B + 2)
+    assert chain.info()["kernel"].endswith("biquad_df1_seq_kernel")
+    for c in range(ch):
+        want = orc.chain_f32(x[c], mode, hi, hq, sin4, cos4, bq)
+        assert rel_rms(got[c], want) < TOL, (spec, c, rel_rms(got[c], want))
+    chain.reset()
+    got2 = run_chain(ctx, chain, x, np.float32, None)
+    assert rel_rms(got2[0], orc.chain_f32(x[0], mode, hi, hq, sin4, cos4, bq)) < TOL

@@ -302,3 +302,36 @@ def test_fir_q15_matrix_core_many_channels_and_segments(ctx, orc, golden, ntaps)
     for c in (0, 1, 2, 37, ch - 1):
         rc, want = orc.fir_q15_blocks(taps, x[c], 128)
         assert rc == 0 and np.array_equal(got[c], want), (ntaps, c)
+
+
+@pytest.mark.parametrize("spec", [[(1, 300, 0.7)], [(1, 300, 0.7), (1, 300, 0.7)], [(1, 1000, 4), (1, 1500, 4), (1, 800, 2)],
+                                  [(3, 1000, 8), (3, 2000, 8), (3, 3000, 8), (3, 4000, 8)], [(0, 5400, 0.54), (3, 3000, 15)]])
+def test_biquad_df1_f32_ill_conditioned_cascades(ctx, orc, spec):
+    """High-pass and narrow-notch cascades: the 'numerators first' parallel evaluation would lose accuracy (two 300 Hz high-pass
+    sections: 8e-3); the library measures the cascade's conditioning and runs such filters in CMSIS order.  Signal with a strong
+    DC term, as an envelope has; many channels, ragged calls, state carried, in place."""
+    rng = np.random.default_rng(len(spec))
+    corr = orclib.AUDIO_SAMPLE_RATE_EXACT / 24000.0
+    coeffs = []
+    for kind, f, q in spec:
+        c = orc.biquad_design(kind, np.float32(f * corr), q).astype(np.float64) / 2 ** 30
+        coeffs.append([c[0], c[1], c[2], -c[3], -c[4]])
+    coeffs = np.array(coeffs, np.float32)
+    ch, n = 70, 6000
+    x = (0.6 + 0.3 * rng.uniform(-1, 1, (ch, n))).astype(np.float32)
+    bq = msdr.BiquadDf1F32(ctx, coeffs, ch)
+    got = np.empty_like(x)
+    for o, m in ((0, 128), (128, 3001), (3129, n - 3129)):
+        d = ctx.to_device(np.ascontiguousarray(x[:, o:o + m]))
+        bq.process(d, d, m)                                       # in place
+        got[:, o:o + m] = d.download()
+    from scipy.signal import lfilter
+    for c in (0, 33, ch - 1):
+        want = orc.biquad_df1_blocks(coeffs, x[c, :(n // 128) * 128], 128)
+        truth = x[c].astype(np.float64)
+        for r in coeffs.astype(np.float64):
+            truth = lfilter(r[:3], [1.0, -r[3], -r[4]], truth)
+        tail = slice(1000, want.size)                             # past the start-up transient of the DC step
+        assert rel_rms(got[c, tail], truth[tail]) < 2e-5, (spec, c)
+        assert rel_rms(got[c, tail], want[tail]) < 2e-5, (spec, c)
+        assert rel_rms(got[c, :want.size], want) < 5e-6, (spec, c)

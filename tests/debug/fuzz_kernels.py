@@ -153,7 +153,13 @@ while time.time() < t_end:
         for c in rng.choice(ch, min(ch, 3), replace=False):
             want = orc.chain_f32(x[c], modes[c], hi, hq, oi, oq, bq)
             err = rel_rms(got[c], want)
-            if not err < 1e-5:
+            # a cascade that removes most of its input turns the 2e-7 agreement in front of it into a larger RELATIVE error of what is
+            # left (any fp32 evaluation does, the oracle included): the bound is referred to the cascade's input level
+            tol = 1e-5
+            if bq is not None:
+                pre = orc.chain_f32(x[c], modes[c], hi, hq, oi, oq, None)
+                tol *= max(1.0, float(np.sqrt((pre.astype(np.float64) ** 2).mean() / max((want.astype(np.float64) ** 2).mean(), 1e-300))))
+            if not err < tol:
                 bad += 1
                 print("MISMATCH f32 chain", dict(seed=seed, case=cases, ntaps=ntaps, ch=ch, n=n, mixer=mixer, P=P, mode=int(modes[c]), stages=stages, err=err,
                                                   kernel=chain.info()["kernel"]))

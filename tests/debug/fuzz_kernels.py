@@ -40,7 +40,7 @@ def splits(n):
 
 
 while time.time() < t_end:
-    which = rng.integers(0, 4)
+    which = rng.integers(0, 5)
     cases += 1
     if which == 0:      # Q15 chain
         ntaps = int(rng.integers(1, 257)) * 2
@@ -164,6 +164,51 @@ while time.time() < t_end:
                 print("MISMATCH f32 chain", dict(seed=seed, case=cases, ntaps=ntaps, ch=ch, n=n, mixer=mixer, P=P, mode=int(modes[c]), stages=stages, err=err,
                                                   kernel=chain.info()["kernel"]))
                 break
+        chain.close()
+    elif which == 4:    # fp32 chain, msdr_chain_set_mode between calls (FIR history and cascade state carry over; folded-numerator modes are entered / left)
+        ntaps = int(rng.integers(2, 200))
+        sets_i = [(rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32) for _ in range(2)]
+        sets_q = [sets_i[0].copy(), (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)]
+        stages = int(rng.integers(0, 3))
+        corr = orclib.AUDIO_SAMPLE_RATE_EXACT / 24000.0
+        bq = None
+        if stages:
+            rows = []
+            for kind, f, q in ((orclib.BQ_LOWPASS, 5400 * corr, 0.54), (orclib.BQ_NOTCH, 3000 * corr, 15.0))[:stages]:
+                c_ = orc.biquad_design(kind, np.float32(f), q).astype(np.float64) / 2 ** 30
+                rows.append([c_[0], c_[1], c_[2], -c_[3], -c_[4]])
+            bq = np.array(rows, np.float32)
+        k = np.arange(B)
+        mixer = int(rng.integers(0, 2))
+        if mixer:
+            oi = (np.round(32767 * np.sin(2 * np.pi * k / 4)).astype(np.int16) / 32768.0).astype(np.float32)
+            oq = (np.round(32767 * np.cos(2 * np.pi * k / 4)).astype(np.int16) / 32768.0).astype(np.float32)
+        else:
+            oi, oq = np.array([0, 1, 0, -1], np.float32)[k % 4], np.array([1, 0, -1, 0], np.float32)[k % 4]
+        ncall = int(rng.integers(2, 7))
+        lens = [int(rng.integers(1, 30)) * B for _ in range(ncall)]
+        x = rand_x(2, sum(lens))
+        mode0, ts0 = int(rng.choice([orclib.AM, orclib.LSB, orclib.USB])), int(rng.integers(0, 2))
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, 2, sets_i, sets_q, mixer=mixer, modes=np.array([mode0, orclib.LSB], np.int32), tapsets=np.array([ts0, 1], np.int32),
+                           osc_i=oi if mixer else None, osc_q=oq if mixer else None, biquad_coeffs=bq)
+        st0, st1, o, ok = {}, {}, 0, True
+        mode, ts = mode0, ts0
+        for j, m in enumerate(lens):
+            if j and rng.integers(0, 3):
+                mode, ts = int(rng.choice([orclib.AM, orclib.LSB, orclib.USB, orclib.CW])), int(rng.integers(0, 2))
+                chain.set_mode(0, mode, ts)
+            seg = np.ascontiguousarray(x[:, o:o + m])
+            dx, dy = ctx.to_device(seg), ctx.array((2, m), np.float32)
+            chain.process(dx, dy, m)
+            got = dy.download()
+            w0 = orc.chain_f32(seg[0], mode, sets_i[ts], sets_q[ts], oi, oq, bq, state=st0)
+            w1 = orc.chain_f32(seg[1], orclib.LSB, sets_i[1], sets_q[1], oi, oq, bq, state=st1)
+            e0, e1 = rel_rms(got[0], w0), rel_rms(got[1], w1)
+            if not (e0 < 1e-5 and e1 < 1e-5):
+                bad += 1
+                print("MISMATCH f32 retune", dict(seed=seed, case=cases, ntaps=ntaps, call=j, mode=mode, ts=ts, stages=stages, mixer=mixer, e0=e0, e1=e1, kernel=chain.info()["kernel"]))
+                break
+            o += m
         chain.close()
     else:               # arm_fir_f32 stage
         ntaps = int(rng.integers(1, 513))

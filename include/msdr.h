@@ -313,6 +313,8 @@ typedef struct {
 #define MSDR_CHAIN_NO_TAP_FOLDING 1u /* F32: keep mixer and FIR pair as separate arithmetic steps (as written) */
 #define MSDR_CHAIN_NO_FFT 4u         /* F32: never use the overlap-save FFT kernel (long FIRs stay sliding dot products) */
 #define MSDR_CHAIN_NO_MFMA 8u        /* never run the FIR on the matrix cores (F32: split-fp16 MFMA kernel; Q15: byte-split i8 MFMA kernel) */
+#define MSDR_CHAIN_FOLD_ANY_PERIOD 64u /* F32, NCO: fold the mixer into the taps (matrix-core kernel) also when the oscillator table's only period is its
+                                         own length (8, 16 or 32 samples); a table that repeats within its length with period 1 .. 32 is folded by default */
 #define MSDR_CHAIN_SYNCAM_PLL 32u    /* Q15: SYNCAM channels run the PLL demodulator (.ino:631-688) instead of the AM branch */
 #define MSDR_CHAIN_MFMA_WG 16u       /* F32: matrix-core kernel with workgroup tiles (msdr_chain_mfma.hiph) instead of one wave per stream */
 

@@ -1239,6 +1239,7 @@ struct msdr_chain {
     float *d_bq_state;
     // folded F32 path (msdr_chain_fold.hiph)
     int fold_P;                       // 0 = not foldable; else NCO period 1, 2 or 4
+    int mf_P;                         // oscillator period the matrix-core tables are built for (1 .. 32, a divisor of the 32-sample output row); 0 = none
     bool fold_fs4_exact;              // oscillator is exactly {1,0,-1,0}/{0,1,0,-1}: AM can be folded too
     float *d_ftaps;                   // [tapsets*3][P rotations][steps][PE rows][2 pair-columns][2]
     int *d_fset;                      // [channels]
@@ -1491,19 +1492,27 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         if (!rc) rc = dzalloc(ctx, (size_t)c->channels * kBqStateFloats, &c->d_bq_state);
     }
     // ---- tap folding (F32): oscillator period, folded tables, per-channel folded-set index ----------
-    c->fold_P = 0; c->fold_fs4_exact = false;
+    c->fold_P = 0; c->fold_fs4_exact = false; c->mf_P = 0;
     if (!rc && f32 && !(cfg->flags & MSDR_CHAIN_NO_TAP_FOLDING)) {
         std::vector<double> oc, os;                       // one period of cos / sin
         if (cfg->mixer == MSDR_MIXER_FS4) { oc = {1, 0, -1, 0}; os = {0, 1, 0, -1}; }
         else {
             const float *fq = (const float *)cfg->osc_q, *fi = (const float *)cfg->osc_i;
-            for (uint32_t P : {1u, 2u, 4u}) {
+            // periods 1, 2, 4: the VALU kernel's per-phase tap tables too; 8, 16, 32 (divisors of the 32-sample output row, so that every
+            // row of a tile sees the same oscillator phases): the matrix-core tables only -- one (H + 32) x 32 block per starting phase
+            for (uint32_t P : {1u, 2u, 4u, 8u, 16u, 32u}) {
                 if (cfg->osc_len % P) continue;
+                // a table that only "repeats" after its own length is folded on request only: the folded evaluation differs from the
+                // as-written one by ~2e-7 of the STRONGER sideband, which shows as > 1e-5 of the output where the wanted sideband is
+                // 40+ dB down (a pure tone on the suppressed side); the as-written kernel tracks the CMSIS order there
+                if (P > 4 && P == cfg->osc_len && !(cfg->flags & MSDR_CHAIN_FOLD_ANY_PERIOD)) continue;
                 bool periodic = true;
                 for (uint32_t k = P; k < cfg->osc_len && periodic; k++) periodic = (fq[k] == fq[k - P]) && (fi[k] == fi[k - P]);
                 if (periodic) { oc.assign(fq, fq + P); os.assign(fi, fi + P); break; }
             }
         }
+        c->mf_P = (int)oc.size();
+        if (oc.size() > 4) oc.clear();                         // no VALU fold tables beyond period 4
         if (!oc.empty()) {
             const int P = (int)oc.size();
             c->fold_P = P;
@@ -1549,9 +1558,9 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     }
     // ---- matrix-core tables (F32, short-period oscillator): B fragments per (tap set x {LSB, USB, envelope}, rotation) ----
     c->mf_ok = false;
-    if (!rc && f32 && c->fold_P > 0 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && mf_halo((int)(c->ntaps + 2 * c->nstages)) <= 2048) {
+    if (!rc && f32 && c->mf_P > 0 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && mf_halo((int)(c->ntaps + 2 * c->nstages)) <= 2048) {
         // SSB tables carry the cascade's numerator C(z) = prod (b0 + b1 z^-1 + b2 z^-2): the FIR grows by 2 taps per section
-        const int P = c->fold_P, N = (int)c->ntaps, NF = N + 2 * (int)c->nstages, H = mf_halo(NF), J = H / 32 + 1, KI = H + 32;
+        const int P = c->mf_P, N = (int)c->ntaps, NF = N + 2 * (int)c->nstages, H = mf_halo(NF), J = H / 32 + 1, KI = H + 32;
         std::vector<double> cnum(1, 1.0);
         for (uint32_t st = 0; st < c->nstages; st++) {
             std::vector<double> nx(cnum.size() + 2, 0.0);
@@ -1708,7 +1717,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                             const int delay = H + b - i;
                             double m0 = 0.0, m1 = 0.0;
                             if (delay >= 0 && delay < nt) {
-                                const int psi = (rot + i) % P;
+                                const int psi = (((rot + i - H) % P) + P) % P;       // window sample i is stream sample t0 - H + i, t0 = 0 (mod P)
                                 if (v == 2) { m0 = di[delay] * oc[psi]; m1 = dq[delay] * os[psi]; }
                                 else m0 = ti[delay] * oc[psi] + (v == 0 ? -1.0 : 1.0) * tq[delay] * os[psi];
                             }
@@ -1963,8 +1972,9 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     const int kTile = use_mfw ? kMwTile : use_mf ? c->mf_waves * kMfWaveTile : use_fft ? kThreads * c->fft_LP : use_fold ? kFoldTile : kChainTile;
     p.mf_tab = c->d_mf_tab; p.mf_stride = c->mf_stride; p.mf_halo = c->mf_halo; p.mf_bsteps = c->mf_bsteps; p.bq_mf = c->d_bq_mf; p.bq_mf32 = c->d_bq_mf32; p.mf_waves = c->mf_waves;
     p.fft_h = c->d_fft_h; p.fft_tw = c->d_fft_tw; p.bq_fft = c->d_bq_fft;
-    p.ftaps = c->d_ftaps; p.chan_fset = c->d_fset; p.fold_period = c->fold_P; p.bq_fold = c->d_bq_fold;
-    p.fold_rot = c->fold_P ? (int)(c->phase % c->fold_P) : 0;
+    const int osc_P = use_mf ? c->mf_P : c->fold_P;            // the matrix-core tables exist for periods up to 32, the VALU fold tables up to 4
+    p.ftaps = c->d_ftaps; p.chan_fset = c->d_fset; p.fold_period = osc_P; p.bq_fold = c->d_bq_fold;
+    p.fold_rot = osc_P ? (int)(c->phase % osc_P) : 0;
 
     // ---- time segmentation (DESIGN.md "IIR along time") ------------------------------------------
     const long long tiles = ((long long)n_samples + kTile - 1) / kTile;

@@ -121,7 +121,7 @@ while time.time() < t_end:
         if (modes == orclib.AM).any() or (modes == orclib.CW).any():
             hq = hi.copy() if rng.integers(0, 2) else hq
         mixer = int(rng.integers(0, 2))
-        P = int(rng.choice([1, 2, 4, 8]))
+        P = int(rng.choice([1, 2, 4, 8, 16, 32, 64]))
         k = np.arange(B)
         if mixer:
             oi = (np.round(32767 * np.sin(2 * np.pi * k / P)).astype(np.int16) / 32768.0).astype(np.float32)

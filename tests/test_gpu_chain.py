@@ -674,3 +674,35 @@ def test_chain_f32_ill_conditioned_cascade_runs_in_cmsis_order(ctx, orc, mode, s
     chain.reset()
     got2 = run_chain(ctx, chain, x, np.float32, None)
     assert rel_rms(got2[0], orc.chain_f32(x[0], mode, hi, hq, sin4, cos4, bq)) < TOL
+
+
+@pytest.mark.parametrize("P,cycles", [(8, 1), (8, 3), (16, 5), (32, 7), (32, 13), (64, 9)])
+def test_chain_f32_longer_oscillator_periods_on_matrix_cores(ctx, orc, P, cycles):
+    """AudioEffectFreqConv tables of period 8, 16, 32 (any frequency cycles * fs / P): the matrix-core kernel takes one folded table
+    per starting phase (the period must divide the 32-sample output row); period 64 keeps the as-written kernel.  SSB and envelope
+    channels, ragged calls."""
+    rng = np.random.default_rng(P + cycles)
+    k = np.arange(128)
+    oi = (np.round(32767 * np.sin(2 * np.pi * cycles * k / P)).astype(np.int16) / 32768.0).astype(np.float32)
+    oq = (np.round(32767 * np.cos(2 * np.pi * cycles * k / P)).astype(np.int16) / 32768.0).astype(np.float32)
+    hi, hq = _hilbert_pair(100)
+    bq = _f32_biquads(orc, 2)
+    modes = np.array([orclib.LSB, orclib.USB, orclib.AM, orclib.LSB], np.int32)
+    ch, n = 4, 30 * B
+    x = rng.integers(-12000, 12001, (ch, n)).astype(np.int16)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, hi, hq, mixer=msdr.MIXER_NCO, modes=modes, osc_i=oi, osc_q=oq, biquad_coeffs=bq,
+                       flags=msdr.CHAIN_FOLD_ANY_PERIOD)
+    got = np.empty((ch, n), np.float32)
+    o = 0
+    for m in (130, 7, 1025, 1, 2, 129, 3, n):
+        m = min(m, n - o)
+        dx, dy = ctx.to_device(np.ascontiguousarray(x[:, o:o + m])), ctx.array((ch, m), np.float32)
+        chain.process(dx, dy, m)
+        got[:, o:o + m] = dy.download()
+        o += m
+        if o >= n:
+            break
+    assert chain.info()["kernel"].startswith("chain_mfw_kernel" if P <= 32 else "chain_kernel<ArithF32>"), chain.info()["kernel"]
+    for c in range(ch):
+        want = orc.chain_f32(x[c], modes[c], hi, hq, oi, oq, bq)
+        assert rel_rms(got[c], want) < TOL, (P, c, rel_rms(got[c], want))

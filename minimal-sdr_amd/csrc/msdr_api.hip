@@ -1702,6 +1702,31 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                     df[l * 8 + j] = vh; df[512 + l * 8 + j] = (_Float16)(val - (double)vh);
                 }
         }
+        // A retune (msdr_chain_set_mode) hands the cascade's state and numerator history of the OLD mode / tap set to the kernel of
+        // the NEW one, which takes them in through fp16 at its own table's scale: the scale of every table must therefore hold
+        // what ANY table of this chain can leave behind, not only its own outputs (a tap set with 20x the gain of its neighbour
+        // used to saturate the first rows after the switch).  Bounds in units of in_scale, like smax / emax below.
+        double chain_d_bound = 0.0, chain_sig_bound = 0.0, oamp = 0.0;
+        for (int k = 0; k < P; k++) oamp = std::max(oamp, std::max(std::fabs(oc[k]), std::fabs(os[k])));
+        if (iirfold) {
+            double cl1 = 0.0, glmax = 0.0;
+            for (double cc : cnum) cl1 += std::fabs(cc);
+            for (int q = 0; q < S_; q++) glmax = std::max(glmax, gl1[q]);
+            for (uint32_t s = 0; s < c->tapsets; s++) {
+                const float *hi = (const float *)cfg->coeffs_i[s], *hq = (const float *)cfg->coeffs_q[s];
+                std::vector<double> gi(NF, 0.0), gq(NF, 0.0);
+                double a = 0.0, b = 0.0, f1 = 0.0;
+                for (int dl = 0; dl < N; dl++) {
+                    a += std::fabs((double)hi[dl]); b += std::fabs((double)hq[dl]);
+                    for (size_t i = 0; i < cnum.size(); i++) { gi[dl + i] += cnum[i] * hi[N - 1 - dl]; gq[dl + i] += cnum[i] * hq[N - 1 - dl]; }
+                }
+                for (int dl = 0; dl < NF; dl++) f1 += std::fabs(gi[dl]) + std::fabs(gq[dl]);
+                const double xs = 32768.0 * oamp * (a + b);                       // |SSB demodulator output| (>= the envelope)
+                const double env = 32768.0 * oamp * std::sqrt(a * a + b * b);     // |envelope|
+                chain_d_bound = std::max(chain_d_bound, xs);
+                chain_sig_bound = std::max(chain_sig_bound, std::max(32768.0 * oamp * f1, env * cl1) * glmax);
+            }
+        }
         for (uint32_t s = 0; s < c->tapsets && ok; s++) {
             const float *hi = (const float *)cfg->coeffs_i[s], *hq = (const float *)cfg->coeffs_q[s];
             // taps by delay (arm_fir keeps its coefficients time-reversed: index N - 1 - delay); plain and numerator-folded
@@ -1750,7 +1775,8 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                         double tl1 = 0.0;
                         for (int dl = 0; dl < nt; dl++) tl1 += std::fabs(ti[dl]) + std::fabs(tq[dl]);
                         double smax = 0.0;
-                        for (int q = 0; q < S_; q++) smax = std::max(smax, 32768.0 * tl1 * gl1[q]);          // |w_q| in units of in_scale
+                        for (int q = 0; q < S_; q++) smax = std::max(smax, 32768.0 * oamp * tl1 * gl1[q]);   // |w_q| in units of in_scale
+                        smax = std::max(smax, chain_sig_bound);
                         while (ex > -8 && smax * std::ldexp(1.0, ex - kMwIirSigExp) > 30000.0) ex--;
                     }
                     const bool fold_am = (v == 2) && amfold;
@@ -1762,10 +1788,11 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                             for (int i = 0; i < KI; i++) { c0 += std::fabs(M[0][(size_t)i * 32 + b]); c1 += std::fabs(M[1][(size_t)i * 32 + b]); }
                             colmax = std::max(colmax, std::sqrt(c0 * c0 + c1 * c1));
                         }
-                        const double emax = 32768.0 * colmax;                    // |envelope| / 2^ex
+                        const double emax = std::max(32768.0 * colmax, chain_d_bound);      // |envelope| / 2^ex, and whatever another mode's numerator history holds
                         double cl1 = 0.0, smax = 0.0;
                         for (double cc : cnum) cl1 += std::fabs(cc);
-                        for (int q = 0; q < S_; q++) smax = std::max(smax, emax * cl1 * gl1[q]);
+                        for (int q = 0; q < S_; q++) smax = std::max(smax, 32768.0 * colmax * cl1 * gl1[q]);
+                        smax = std::max(smax, chain_sig_bound);
                         while (ex > -8 && (emax * std::ldexp(1.0, ex - kMwIirEnvExp) > 30000.0 || smax * std::ldexp(1.0, ex - kMwIirSigExp) > 30000.0)) ex--;
                     }
                     const double scale = std::ldexp(1.0, ex);

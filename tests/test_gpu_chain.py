@@ -445,6 +445,36 @@ def test_chain_f32_retune_mid_stream_keeps_cascade_state(ctx, orc, engine):
         assert rel_rms(got[1], want1) < TOL, (k, rel_rms(got[1], want1))
 
 
+@pytest.mark.parametrize("stages", [1, 2])
+@pytest.mark.parametrize("ntaps", [3, 40])
+def test_chain_f32_retune_between_tap_sets_of_very_different_gain(ctx, orc, stages, ntaps):
+    """The cascade's state and numerator history that one (mode, tap set) leaves behind enter the next one's kernel through
+    fp16 at the NEW table's scale.  A loud tap set followed by one with 1/50 of its gain used to saturate there (first rows
+    after the switch wrong by 2-30 %; found by tests/debug/fuzz_retune.py): the table scales are bounded chain-wide now."""
+    rng = np.random.default_rng(77)
+    loud_i = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    loud_q = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    quiet = (0.02 * rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    sets_i, sets_q = [quiet, loud_i], [quiet.copy(), loud_q]
+    bq = _f32_biquads(orc, stages)
+    cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+    plan = [(orclib.CW, 1), (orclib.AM, 0), (orclib.USB, 1), (orclib.LSB, 0), (orclib.AM, 1), (orclib.CW, 0), (orclib.LSB, 1), (orclib.AM, 0)]
+    x = rng.integers(-20000, 20001, (2, 1408 * len(plan))).astype(np.int16)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 2, sets_i, sets_q, mixer=msdr.MIXER_FS4, modes=np.array([plan[0][0], orclib.LSB], np.int32),
+                       tapsets=np.array([plan[0][1], 1], np.int32), biquad_coeffs=bq)
+    st0, st1 = {}, {}
+    for k, (m, ts) in enumerate(plan):
+        if k:
+            chain.set_mode(0, m, ts)
+        seg = x[:, 1408 * k:1408 * (k + 1)]
+        got = run_chain(ctx, chain, seg, np.float32)
+        assert chain.info()["kernel"].startswith("chain_mfw_kernel")
+        want0 = orc.chain_f32(seg[0], m, sets_i[ts], sets_q[ts], sin4, cos4, bq, state=st0)
+        want1 = orc.chain_f32(seg[1], orclib.LSB, sets_i[1], sets_q[1], sin4, cos4, bq, state=st1)
+        assert rel_rms(got[0], want0) < TOL, (k, m, ts, rel_rms(got[0], want0))
+        assert rel_rms(got[1], want1) < TOL, (k, rel_rms(got[1], want1))
+
+
 def test_chain_f32_mfw_repeatable_long_stream(ctx, orc):
     """Many short segments, a long halo (256 taps) and the folded IIR: every launch must give the same, correct stream.  (A
     variant of the kernel that took the scan's uniform matrices through the scalar cache gave intermittently wrong rows

@@ -313,8 +313,9 @@ class Oracle:
 
     # ---- chains -------------------------------------------------------------------------
     def chain_q15(self, x, mode, coeffs_i, coeffs_q, mixer=0, osc_i=None, osc_q=None,
-                  sqrt_kind=SQRT_F32, biquads=(), want_iq=False):
-        """One channel, len(x) a multiple of BLOCK. biquads = list of BiquadTeensy nodes (copied)."""
+                  sqrt_kind=SQRT_F32, biquads=(), want_iq=False, state=None):
+        """One channel, len(x) a multiple of BLOCK. biquads = list of BiquadTeensy nodes (copied).
+        `state` = dict carried between calls (FIR states, biquad nodes): the stream continues where the last call stopped."""
         x = np.ascontiguousarray(x, np.int16)
         assert x.size % BLOCK == 0
         ci = np.ascontiguousarray(coeffs_i, np.int16)
@@ -323,17 +324,26 @@ class Oracle:
         oq = np.ascontiguousarray(osc_q, np.int16) if osc_q is not None else None
         cfg = ChainQ15Cfg(int(mode), int(sqrt_kind), int(mixer), ci.size, _ptr(ci), _ptr(cq),
                           _ptr(oi), _ptr(oq), len(biquads), None)
-        si = np.zeros(ci.size + BLOCK, np.int16)
-        sq = np.zeros(ci.size + BLOCK, np.int16)
+        if state is None:
+            state = {}
+        si = state.setdefault("si", np.zeros(ci.size + BLOCK, np.int16))
+        sq = state.setdefault("sq", np.zeros(ci.size + BLOCK, np.int16))
         st = ChainQ15State()
         st.state_i, st.state_q = _ptr(si), _ptr(sq)
-        for k, b in enumerate(biquads):
+        for k, b in enumerate(state.get("bq", biquads)):
             C.memmove(C.byref(st.bq[k]), C.byref(b), C.sizeof(BiquadTeensy))
         audio = np.empty_like(x)
         io = np.empty_like(x) if want_iq else None
         qo = np.empty_like(x) if want_iq else None
         self.lib.orc_chain_q15(C.byref(cfg), C.byref(st), _ptr(x), _ptr(audio), _ptr(io), _ptr(qo),
                                C.c_uint32(x.size // BLOCK))
+        if biquads:
+            keep = []
+            for k in range(len(biquads)):
+                b = BiquadTeensy()
+                C.memmove(C.byref(b), C.byref(st.bq[k]), C.sizeof(BiquadTeensy))
+                keep.append(b)
+            state["bq"] = keep
         return (audio, io, qo) if want_iq else audio
 
     def _f32_cfg(self, mode, coeffs_i, coeffs_q, osc_i, osc_q, bq_coeffs, in_scale):

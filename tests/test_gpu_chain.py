@@ -588,6 +588,46 @@ def test_chain_q15_matrix_core_time_segments_and_tapsets(ctx, orc, golden):
     assert np.array_equal(got[0][512:], want[512:])
 
 
+@pytest.mark.parametrize("mixer", [0, 1])
+def test_chain_q15_retune_mid_stream_is_bit_exact(ctx, orc, golden, mixer):
+    """msdr_chain_set_mode between calls on the Q15 chain: the FIR history (raw IF samples, mixed again at staging) and the two
+    biquad nodes' state carry over, the channel groups per (tap set, demodulator) are rebuilt -- bit-exact against the oracle
+    run with a carried state.  (tests/debug/fuzz_retune_q15.py is the randomised version: 56 000 plans, 0 mismatches.)"""
+    rng = np.random.default_rng(90 + mixer)
+    ch = 70
+    pad = lambda t: np.concatenate([np.zeros(102 - t.size, np.int16), t])
+    sets_i = [golden["fir/taps_am102"], pad(golden["taps/FIR_SSB_I_coeffs"]), pad(golden["taps/FIR_CW_I_coeffs"])]
+    sets_q = [golden["fir/taps_am102"], pad(golden["taps/FIR_SSB_Q_coeffs"]), pad(golden["taps/FIR_CW_Q_coeffs"])]
+    lp, nt = _ref_nodes(orc)
+    oi = oq = None
+    if mixer:
+        k = np.arange(B)
+        oi = np.round(32767 * np.sin(2 * np.pi * k / 4)).astype(np.int16)
+        oq = np.round(32767 * np.cos(2 * np.pi * k / 4)).astype(np.int16)
+    modes = rng.integers(1, 5, ch).astype(np.int32)
+    tapsets = rng.integers(0, 3, ch).astype(np.int32)
+    lens = [5 * B, B, 9 * B, 3 * B, 6 * B]
+    x = rng.integers(-20000, 20001, (ch, sum(lens))).astype(np.int16)
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, sets_i, sets_q, mixer=mixer, modes=modes, tapsets=tapsets, osc_i=oi, osc_q=oq,
+                       biquad_nodes=[[lp], [nt]])
+    watch = [0, 1, 17, 63, 64, 69]
+    states = {c: {} for c in watch}
+    o = 0
+    for j, m in enumerate(lens):
+        if j:
+            for c in watch[j % 2::2] + [5, 40]:                      # half of the watched channels, and two unwatched ones
+                modes[c], tapsets[c] = int(rng.integers(1, 5)), int(rng.integers(0, 3))
+                chain.set_mode(c, int(modes[c]), int(tapsets[c]))
+        seg = np.ascontiguousarray(x[:, o:o + m])
+        got = run_chain(ctx, chain, seg, np.int16)
+        assert chain.info()["kernel"].startswith(QM)
+        for c in watch:
+            want = orc.chain_q15(seg[c], int(modes[c]), sets_i[tapsets[c]], sets_q[tapsets[c]], mixer=mixer, osc_i=oi, osc_q=oq,
+                                 biquads=[orc.biquad_teensy_new([lp]), orc.biquad_teensy_new([nt])], state=states[c])
+            assert np.array_equal(got[c], want), (j, c, int(modes[c]), int(tapsets[c]))
+        o += m
+
+
 @pytest.mark.parametrize("ch", [64, 192])
 def test_chain_q15_two_biquad_nodes_pipeline(ctx, orc, golden, ch):
     """biquad1_dac -> biquad2_dac on whole 64-channel groups runs as a two-wave pipeline (one node per wave): multi-stage nodes,

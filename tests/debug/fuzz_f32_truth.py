@@ -17,6 +17,7 @@ import orclib  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+LONG = os.environ.get("FUZZ_LONG", "0") == "1"      # one channel, 2^17 .. 2^20 samples per call, Q up to 20: the automatic time segmentation
 orc = orclib.Oracle()
 ctx = msdr.Context(0)
 B = 128
@@ -49,6 +50,8 @@ while time.time() < t_end:
     ntaps = int(rng.integers(2, 300))
     ch = int(rng.choice([1, 3, 40]))
     n = int(rng.integers(2, 80)) * B
+    if LONG:
+        ch, n = 1, int(rng.integers(1 << 10, 1 << 13)) * B
     hi = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
     hq = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
     modes = rng.choice([orclib.AM, orclib.LSB, orclib.USB, orclib.CW], ch).astype(np.int32)
@@ -66,7 +69,7 @@ while time.time() < t_end:
     rows = []
     for _ in range(stages):
         kind = int(rng.choice([orclib.BQ_LOWPASS, orclib.BQ_NOTCH, orclib.BQ_HIGHPASS]))
-        c_ = orc.biquad_design(kind, np.float32(rng.uniform(800, 9000)), float(rng.uniform(0.5, 8))).astype(np.float64) / 2 ** 30
+        c_ = orc.biquad_design(kind, np.float32(rng.uniform(800, 9000)), float(rng.uniform(0.5, 20 if LONG else 8))).astype(np.float64) / 2 ** 30
         rows.append([c_[0], c_[1], c_[2], -c_[3], -c_[4]])
     bq = np.array(rows, np.float32)
     kindx = rng.integers(0, 3)
@@ -88,8 +91,9 @@ while time.time() < t_end:
         worst = max(worst, e_gpu / max(e_orc, 1e-12))
         bad = e_gpu > 2 * e_orc + 1e-6
         defects += bad
-        print("%s case %d: gpu-oracle %.2e | gpu-f64 %.2e  oracle-f64 %.2e | taps %d stages %d P %d mixer %d mode %d %s"
-              % ("DEFECT" if bad else "inherent", case, e_go, e_gpu, e_orc, ntaps, stages, P, mixer, int(modes[c]), chain.info()["kernel"]), flush=True)
+        print("%s case %d: gpu-oracle %.2e | gpu-f64 %.2e  oracle-f64 %.2e | taps %d stages %d P %d mixer %d mode %d %s n %d segs %d"
+              % ("DEFECT" if bad else "inherent", case, e_go, e_gpu, e_orc, ntaps, stages, P, mixer, int(modes[c]), chain.info()["kernel"], n,
+                 chain.info()["time_segments"]), flush=True)
     chain.close()
 print("fuzz_f32_truth done: %d cases, %d over 1e-5 vs the fp32 oracle, %d of them further from float64 than the oracle is (worst e_gpu/e_orc %.2f), seed %d"
       % (case, over, defects, worst, seed))

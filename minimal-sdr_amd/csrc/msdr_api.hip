@@ -333,6 +333,51 @@ static double cascade_condition(const float *coeffs, int stages)
 // are within a small factor of each other.  The reference's own cascade (LP Q 0.54 + notch Q 15) has kappa 19.
 constexpr double kCascadeConditionLimit = 30.0;
 
+// How noisy the cascade is in fp32 whatever the order of evaluation: the distance of the sequential df1 evaluation (CMSIS order,
+// separately rounded products and sums) from a double evaluation on a fixed test signal (white noise on a DC term, 8192 samples).
+// 4e-7 for the reference's cascade; 1e-5 and more when narrow resonances ring for hundreds of samples.  The block-parallel
+// solver's dot products with the all-pole impulse response lose kappa times that (measured, tests/debug/fuzz_stage_df1.py:
+// kappa 20 x 1.4e-5 -> 4.5e-4), so the product of the two is what decides -- see cascade_needs_cmsis_order().
+static double cascade_fp32_noise(const float *coeffs, int stages)
+{
+    const int N = 8192;
+    float sf[kMaxStages][4] = {{0}};
+    double sd[kMaxStages][4] = {{0}};
+    double num = 0.0, den = 0.0;
+    uint32_t lcg = 12345u;
+    for (int n = 0; n < N; n++) {
+        double u = 0.0;
+        for (int k = 0; k < 4; k++) { lcg = lcg * 1664525u + 1013904223u; u += (double)(lcg >> 8) * (1.0 / 16777216.0); }
+        const float xin = (float)(1.0 + (u - 2.0) * 1.7320508);          // unit variance (sum of four uniforms), mean 1
+        volatile float df = xin;                                          // volatile: every product and sum rounded to fp32, no contraction
+        double dd = (double)xin;
+        for (int s = 0; s < stages; s++) {
+            const float *c = coeffs + 5 * s;
+            volatile float p0 = c[0] * df, p1 = c[1] * sf[s][0], p2 = c[2] * sf[s][1], p3 = c[3] * sf[s][2], p4 = c[4] * sf[s][3];
+            volatile float a = p0 + p1; a = a + p2; a = a + p3; a = a + p4;
+            sf[s][1] = sf[s][0]; sf[s][0] = df; sf[s][3] = sf[s][2]; sf[s][2] = a;
+            df = a;
+            const double yd = (double)c[0] * dd + (double)c[1] * sd[s][0] + (double)c[2] * sd[s][1] + (double)c[3] * sd[s][2] + (double)c[4] * sd[s][3];
+            sd[s][1] = sd[s][0]; sd[s][0] = dd; sd[s][3] = sd[s][2]; sd[s][2] = yd;
+            dd = yd;
+        }
+        if (!std::isfinite(dd) || !std::isfinite((double)df)) return 1e30;
+        num += ((double)df - dd) * ((double)df - dd); den += dd * dd;
+    }
+    return den > 0 ? std::sqrt(num / den) : 0.0;
+}
+constexpr double kCascadeParallelErrorLimit = 2e-5;     // kappa x fp32 noise; the reference's cascade: 19 x 4e-7 = 8e-6
+
+static bool cascade_needs_cmsis_order(const float *coeffs, int stages)
+{
+    if (stages <= 0) return false;
+    const double kappa = cascade_condition(coeffs, stages);
+    const double noise = cascade_fp32_noise(coeffs, stages);
+    const bool seq = kappa > kCascadeConditionLimit || kappa * noise > kCascadeParallelErrorLimit;
+    if (getenv("MSDR_DEBUG_CONDITION")) fprintf(stderr, "msdr: cascade of %d sections: kappa %.3g, fp32 noise %.3g -> %s\n", stages, kappa, noise, seq ? "CMSIS order" : "parallel");
+    return seq;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Q15 on the integer matrix cores (msdr_chain_q15mf.hiph): byte-split Toeplitz fragments per (tap set, phase mod 4).
 // par[o] = parity of the mixer phases that feed accumulator o (I, Q); fir_only: one filter over every sample (the FIR stage).
@@ -679,7 +724,7 @@ extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, cons
     S->ctx = ctx; S->channels = channels; S->stages = numStages; S->d_tabs = nullptr; S->d_state = nullptr; S->d_state_alt = nullptr;
     S->pole_radius = numStages ? max_pole_radius(pCoeffs, (int)numStages) : 0.0;
     S->d_coeffs = nullptr;
-    S->sequential = numStages > 0 && (cascade_condition(pCoeffs, (int)numStages) > kCascadeConditionLimit || getenv("MSDR_BIQUAD_SEQUENTIAL"));
+    S->sequential = numStages > 0 && (cascade_needs_cmsis_order(pCoeffs, (int)numStages) || getenv("MSDR_BIQUAD_SEQUENTIAL"));
     if (S->sequential) {
         std::vector<float> cf(pCoeffs, pCoeffs + 5 * numStages);
         if (int rc = upload(ctx, cf, &S->d_coeffs)) { delete S; return rc; }
@@ -1354,7 +1399,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     if (!mode_ok(cfg->default_mode)) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad default_mode");
 
     if (f32 && cfg->num_biquad_stages &&
-        (cascade_condition(cfg->biquad_coeffs, (int)cfg->num_biquad_stages) > kCascadeConditionLimit || getenv("MSDR_BIQUAD_SEQUENTIAL"))) {
+        (cascade_needs_cmsis_order(cfg->biquad_coeffs, (int)cfg->num_biquad_stages) || getenv("MSDR_BIQUAD_SEQUENTIAL"))) {
         // the parallel "numerators first" evaluation would lose accuracy on this cascade (cascade_condition): build the chain without
         // it and run arm_biquad_cascade_df1_f32 as written behind the main kernel (one lane per channel)
         msdr_chain_config plain = *cfg;

@@ -709,6 +709,8 @@ struct msdr_biquad_df1_f32 {
     double pole_radius;
     bool sequential;      // ill-conditioned for the parallel evaluation (cascade_condition): biquad_df1_seq_kernel, CMSIS order
     float *d_coeffs;      // sequential: the 5 x stages coefficients
+    float *d_seq_scratch; // sequential, few channels x long block: the segments' warm-up samples (biquad_seqseg_gather_kernel)
+    size_t seq_scratch_floats;
 };
 
 extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, const float32_t *pCoeffs, uint32_t channels,
@@ -723,7 +725,7 @@ extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, cons
     if (!S) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
     S->ctx = ctx; S->channels = channels; S->stages = numStages; S->d_tabs = nullptr; S->d_state = nullptr; S->d_state_alt = nullptr;
     S->pole_radius = numStages ? max_pole_radius(pCoeffs, (int)numStages) : 0.0;
-    S->d_coeffs = nullptr;
+    S->d_coeffs = nullptr; S->d_seq_scratch = nullptr; S->seq_scratch_floats = 0;
     S->sequential = numStages > 0 && (cascade_needs_cmsis_order(pCoeffs, (int)numStages) || getenv("MSDR_BIQUAD_SEQUENTIAL"));
     if (S->sequential) {
         std::vector<float> cf(pCoeffs, pCoeffs + 5 * numStages);
@@ -749,6 +751,34 @@ extern "C" int msdr_biquad_df1_f32_process(msdr_biquad_df1_f32 *S, const float32
         return 0;
     }
     if (S->sequential) {
+        // few channels and a long block: one lane per (channel, time segment), each segment warmed up over the samples in front of
+        // it (copied aside first, so in place stays allowed); the warm-up length follows from the slowest pole (1e-10 of the state)
+        long long nseg = 1, seg_len = blockSize, warm = 0;
+        if (S->channels < 8192 && S->pole_radius > 0.0 && S->pole_radius < 0.99999 && !getenv("MSDR_BIQUAD_SEQ_NO_SEGMENTS")) {
+            warm = ((long long)std::ceil(std::log(1e-10) / std::log(S->pole_radius)) + 64 * S->stages + 3) & ~3LL;
+            const long long min_len = std::max<long long>(8 * warm, 1024);
+            const long long want = (65536 + S->channels - 1) / S->channels;
+            nseg = std::max<long long>(1, std::min(want, (long long)blockSize / min_len));
+            seg_len = (((long long)blockSize + nseg - 1) / nseg + 3) & ~3LL;
+            nseg = ((long long)blockSize + seg_len - 1) / seg_len;
+        }
+        if (nseg > 1) {
+            const size_t need = (size_t)S->channels * (size_t)nseg * (size_t)warm;
+            if (need > S->seq_scratch_floats) {
+                HIP_TRY(hipStreamSynchronize(S->ctx->stream));
+                hipFree(S->d_seq_scratch); S->d_seq_scratch = nullptr; S->seq_scratch_floats = 0;
+                HIP_TRY(hipMalloc((void **)&S->d_seq_scratch, need * sizeof(float)));
+                S->seq_scratch_floats = need;
+            }
+            hipLaunchKernelGGL(biquad_seqseg_gather_kernel, dim3((unsigned)std::min<size_t>((need + 255) / 256, 65536)), dim3(256), 0, S->ctx->stream,
+                               d_src, S->d_seq_scratch, (long long)blockSize, (int)S->channels, (int)nseg, seg_len, (int)warm);
+            if (int rc = launch_check("biquad_seqseg_gather_kernel")) return rc;
+            hipLaunchKernelGGL(biquad_df1_seqseg_kernel, dim3((unsigned)(((long long)S->channels * nseg + 63) / 64)), dim3(64), 0, S->ctx->stream,
+                               d_src, d_dst, (long long)blockSize, (int)S->channels, (int)S->stages, (const float *)S->d_coeffs,
+                               (const float *)S->d_state, S->d_state_alt, (int)nseg, seg_len, (int)warm, (const float *)S->d_seq_scratch);
+            std::swap(S->d_state, S->d_state_alt);
+            return launch_check("biquad_df1_seqseg_kernel");
+        }
         hipLaunchKernelGGL(biquad_df1_seq_kernel, dim3((S->channels + 63) / 64), dim3(64), 0, S->ctx->stream, d_src, d_dst, (long long)blockSize,
                            (int)S->channels, (int)S->stages, (const float *)S->d_coeffs, S->d_state);
         return launch_check("biquad_df1_seq_kernel");
@@ -785,7 +815,7 @@ extern "C" int msdr_biquad_df1_f32_destroy(msdr_biquad_df1_f32 *S)
     if (!S) return 0;
     if (int rc = bind(S->ctx)) return rc;
     (void)hipStreamSynchronize(S->ctx->stream);
-    hipFree(S->d_tabs); hipFree(S->d_state); hipFree(S->d_state_alt); hipFree(S->d_coeffs);
+    hipFree(S->d_tabs); hipFree(S->d_state); hipFree(S->d_state_alt); hipFree(S->d_coeffs); hipFree(S->d_seq_scratch);
     delete S;
     return 0;
 }

@@ -776,3 +776,29 @@ def test_chain_f32_longer_oscillator_periods_on_matrix_cores(ctx, orc, P, cycles
     for c in range(ch):
         want = orc.chain_f32(x[c], modes[c], hi, hq, oi, oq, bq)
         assert rel_rms(got[c], want) < TOL, (P, c, rel_rms(got[c], want))
+
+
+def test_chain_f32_cmsis_order_cascade_on_one_long_stream(ctx, orc):
+    """An AM channel with a 300 Hz high-pass pair behind the envelope (DC removal: ill-conditioned for the parallel IIR), ONE
+    channel, two calls of ~2^20 samples: the CMSIS-order cascade behind the main kernel runs in time segments, in place on the
+    audio buffer, state carried between the calls."""
+    rng = np.random.default_rng(23)
+    k = np.arange(100)
+    proto = np.sinc(1920 / 24000 * (k - 49.5)) * np.kaiser(100, 6.0)
+    lp = (proto / proto.sum()).astype(np.float32)
+    cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+    c_ = orc.biquad_design(orclib.BQ_HIGHPASS, np.float32(300 * CORR), 0.7).astype(np.float64) / 2 ** 30
+    bq = np.array([[c_[0], c_[1], c_[2], -c_[3], -c_[4]]] * 2, np.float32)
+    lens = [(1 << 20) + 5 * B, (1 << 20) - 3 * B]
+    t = np.arange(sum(lens))
+    x = (np.round(9000 * (1 + 0.5 * np.cos(2 * np.pi * 700 * t / 24000)) * np.cos(2 * np.pi * 6000 * t / 24000))
+         + rng.integers(-300, 301, t.size)).astype(np.int16)[None, :]
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 1, lp, lp, mode=orclib.AM, biquad_coeffs=bq)
+    st, o = {}, 0
+    for m in lens:
+        seg = np.ascontiguousarray(x[:, o:o + m])
+        got = run_chain(ctx, chain, seg, np.float32)
+        assert chain.info()["kernel"].endswith("biquad_df1_seq_kernel")
+        want = orc.chain_f32(seg[0], orclib.AM, lp, lp, sin4, cos4, bq, state=st)
+        assert rel_rms(got[0], want) < TOL, (o, rel_rms(got[0], want))
+        o += m

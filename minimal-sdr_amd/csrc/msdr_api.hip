@@ -367,13 +367,16 @@ static double cascade_fp32_noise(const float *coeffs, int stages)
     return den > 0 ? std::sqrt(num / den) : 0.0;
 }
 constexpr double kCascadeParallelErrorLimit = 2e-5;     // kappa x fp32 noise; the reference's cascade: 19 x 4e-7 = 8e-6
+// A cascade that is this noisy in the sequential order already (5 x the reference's) leaves no room: the parallel solver was 2-10 x
+// the oracle's distance from float64 on such filters (resonant sections below 1 kHz), whatever kappa says.
+constexpr double kCascadeNoiseLimit = 2e-6;
 
 static bool cascade_needs_cmsis_order(const float *coeffs, int stages)
 {
     if (stages <= 0) return false;
     const double kappa = cascade_condition(coeffs, stages);
     const double noise = cascade_fp32_noise(coeffs, stages);
-    const bool seq = kappa > kCascadeConditionLimit || kappa * noise > kCascadeParallelErrorLimit;
+    const bool seq = kappa > kCascadeConditionLimit || kappa * noise > kCascadeParallelErrorLimit || noise > kCascadeNoiseLimit;
     if (getenv("MSDR_DEBUG_CONDITION")) fprintf(stderr, "msdr: cascade of %d sections: kappa %.3g, fp32 noise %.3g -> %s\n", stages, kappa, noise, seq ? "CMSIS order" : "parallel");
     return seq;
 }

@@ -718,6 +718,15 @@ struct msdr_biquad_df1_f32 {
     size_t seq_scratch_floats;
 };
 
+extern "C" int msdr_biquad_df1_f32_cascade_info(uint8_t numStages, const float32_t *pCoeffs, double *kappa, double *fp32_noise, int *cmsis_order)
+{
+    if (numStages > kMaxStages) return fail(MSDR_STATUS_ARGUMENT_ERROR, "numStages %u > %d", (unsigned)numStages, kMaxStages);
+    if (numStages && !pCoeffs) return fail(MSDR_STATUS_ARGUMENT_ERROR, "pCoeffs is null");
+    if (kappa) *kappa = cascade_condition(pCoeffs, (int)numStages);
+    if (fp32_noise) *fp32_noise = numStages ? cascade_fp32_noise(pCoeffs, (int)numStages) : 0.0;
+    if (cmsis_order) *cmsis_order = (numStages && (cascade_needs_cmsis_order(pCoeffs, (int)numStages) || getenv("MSDR_BIQUAD_SEQUENTIAL"))) ? 1 : 0;
+    return 0;
+}
 extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, const float32_t *pCoeffs, uint32_t channels,
                                           msdr_biquad_df1_f32 **out)
 {

@@ -71,6 +71,7 @@ def load_library(path=None):
         _lib.msdr_calc_FIR_coeffs.restype = None
         _lib.msdr_calc_FIR_coeffs.argtypes = [_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
         _lib.msdr_biquad_design.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_double, _p]
+        _lib.msdr_biquad_df1_f32_cascade_info.argtypes = [C.c_uint8, _p, _p, _p, _p]
         _lib.msdr_malloc.argtypes = [_p, C.c_size_t, _p]
         _lib.msdr_free.argtypes = [_p, _p]
         _lib.msdr_memcpy_h2d.argtypes = [_p, _p, _p, C.c_size_t]
@@ -126,6 +127,14 @@ def biquad_design(kind, freq, q_or_gain, slope=1.0, fs=AUDIO_SAMPLE_RATE_EXACT):
     c = np.zeros(5, np.int32)
     _ck(load_library().msdr_biquad_design(int(kind), float(freq), float(q_or_gain), float(slope), float(fs), _hp(c)))
     return c
+
+
+def biquad_cascade_info(coeffs):
+    """(kappa, fp32_noise, cmsis_order) of a df1 cascade {b0,b1,b2,a1,a2} x stages -- host only."""
+    c = np.ascontiguousarray(coeffs, np.float32).reshape(-1)
+    k, nz, seq = C.c_double(0), C.c_double(0), C.c_int(0)
+    _ck(load_library().msdr_biquad_df1_f32_cascade_info(C.c_uint8(c.size // 5), _hp(c) if c.size else None, C.byref(k), C.byref(nz), C.byref(seq)))
+    return k.value, nz.value, bool(seq.value)
 
 
 class DeviceView:

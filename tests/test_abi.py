@@ -13,6 +13,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "minimal-sdr_amd", "python"))
 import msdr  # noqa: E402
+import orclib  # noqa: E402
 
 
 def declared_functions():
@@ -99,3 +100,26 @@ def test_rfft_init_check_mirrors_arm_rfft_init_q15():
     for n in (32, 64, 256, 8192):                            # valid for CMSIS, not built here
         assert lib.msdr_rfft_q15_init_check(n, 0, 1) == -2
     assert lib.msdr_rfft_q15_init_check(128, 1, 1) == -2
+
+
+def test_cascade_info_routes_the_reference_cascade_to_the_parallel_solver(orc):
+    """msdr_biquad_df1_f32_cascade_info (host only): the reference's LP + notch cascade and the Linkwitz-Riley set stay on the
+    block-parallel IIR, high-pass pairs and narrow low-frequency notches go to CMSIS order."""
+    corr = orclib.AUDIO_SAMPLE_RATE_EXACT / 24000.0
+    LP, HP, NT = orclib.BQ_LOWPASS, orclib.BQ_HIGHPASS, orclib.BQ_NOTCH
+
+    def rows(specs):
+        out = []
+        for kind, f, q in specs:
+            c = orc.biquad_design(kind, np.float32(f), q).astype(np.float64) / 2 ** 30
+            out.append([c[0], c[1], c[2], -c[3], -c[4]])
+        return np.array(out, np.float32)
+
+    k, nz, seq = msdr.biquad_cascade_info(rows([(LP, 5400 * corr, 0.54), (NT, 3000 * corr, 15.0)]))      # Minimal-SDR.ino:356, :391-393
+    assert 15 < k < 25 and 1e-7 < nz < 1e-6 and not seq
+    k, nz, seq = msdr.biquad_cascade_info(rows([(LP, 5400 * corr, q) for q in (0.54, 1.3, 0.54, 1.3)]))   # .ino:393-399
+    assert k < 10 and not seq
+    assert msdr.biquad_cascade_info(rows([(HP, 300.0, 0.707)]))[2]
+    assert msdr.biquad_cascade_info(rows([(HP, 300.0, 0.707)] * 2))[0] > 1e4
+    assert msdr.biquad_cascade_info(rows([(NT, 300.0, 20.0), (LP, 5000.0, 0.7)]))[2]
+    assert msdr.biquad_cascade_info(np.zeros((0, 5), np.float32)) == (1.0, 0.0, False)

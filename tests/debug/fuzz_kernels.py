@@ -15,7 +15,22 @@ orc = orclib.Oracle()
 ctx = msdr.Context(0)
 B = 128
 t_end = time.time() + budget
-cases = bad = 0
+cases = bad = inherent = 0
+
+
+def truth64(x, mode, hi, hq, oi, oq, bq):
+    """orc_chain_f32 (oracle/msdr_oracle.c) with every operation in float64."""
+    from scipy.signal import lfilter
+    n = np.arange(x.size)
+    xf = x.astype(np.float64) * (1.0 / 32768)
+    wi, wq = xf * oq.astype(np.float64)[n % oq.size], xf * oi.astype(np.float64)[n % oi.size]
+    ai = lfilter(hi.astype(np.float64)[::-1], [1.0], wi)
+    aq = lfilter(hq.astype(np.float64)[::-1], [1.0], wq)
+    d = ai - aq if mode == orclib.LSB else ai + aq if mode == orclib.USB else np.sqrt(ai * ai + aq * aq)
+    if bq is not None:
+        for c in np.asarray(bq, np.float64):
+            d = lfilter(c[:3], [1.0, -c[3], -c[4]], d)
+    return d
 
 
 def rand_x(ch, n):
@@ -160,6 +175,12 @@ while time.time() < t_end:
                 pre = orc.chain_f32(x[c], modes[c], hi, hq, oi, oq, None)
                 tol *= max(1.0, float(np.sqrt((pre.astype(np.float64) ** 2).mean() / max((want.astype(np.float64) ** 2).mean(), 1e-300))))
             if not err < tol:
+                # beyond the tolerance of the fp32 oracle: a defect only if the library is further from a float64 evaluation than the
+                # oracle itself is (resonant / deep-stop-band cascades: any fp32 evaluation is noisy; see fuzz_f32_truth.py)
+                t64 = truth64(x[c], int(modes[c]), hi, hq, oi, oq, bq)
+                if rel_rms(got[c], t64) <= 2 * rel_rms(want, t64) + 1e-6:
+                    inherent += 1
+                    continue
                 bad += 1
                 print("MISMATCH f32 chain", dict(seed=seed, case=cases, ntaps=ntaps, ch=ch, n=n, mixer=mixer, P=P, mode=int(modes[c]), stages=stages, err=err,
                                                   kernel=chain.info()["kernel"]))
@@ -232,5 +253,5 @@ while time.time() < t_end:
         fir.close()
     if cases % 50 == 0:
         print("cases", cases, "bad", bad, flush=True)
-print("fuzz done: %d cases, %d mismatches (seed %d)" % (cases, bad, seed))
+print("fuzz done: %d cases, %d mismatches (seed %d); %d fp32-chain checks beyond the oracle tolerance where the oracle is as far from float64" % (cases, bad, seed, inherent))
 sys.exit(1 if bad else 0)

@@ -99,6 +99,12 @@ int msdr_memset(msdr_ctx *ctx, void *d_dst, int value, size_t bytes);
  * types 2/3 write numCoeffs+1, type 4 (Hilbert) writes up to 2*numCoeffs+2. */
 void msdr_calc_FIR_coeffs(int16_t *coeffs, int numCoeffs, float32_t fc, float32_t Astop, int type,
                           float dfc, float Fsamprate);
+/* The sketch takes `PI` from outside (PIH = PI / 2, .ino:779).  msdr_calc_FIR_coeffs evaluates it as the vendored CMSIS
+ * header's float fallback (src/CMSIS_5/arm_math.h:365-367); on a Teensy, Arduino.h's double literal is defined first and
+ * `m * PIH` etc. are then evaluated in double, which moves single taps by 1 LSB after the truncation to int16.
+ * msdr_calc_FIR_coeffs_pid is that variant.  Both are bit-exact against the compiled reference built with the matching PI. */
+void msdr_calc_FIR_coeffs_pid(int16_t *coeffs, int numCoeffs, float32_t fc, float32_t Astop, int type,
+                              float dfc, float Fsamprate);
 /* AudioFilterBiquad::setLowpass/.../setHighShelf, src/Audio/filter_biquad.h:56-149.
  * coef[5] = {b0,b1,b2,a1,a2} scaled by 2^30 in textbook sign, exactly what the reference hands
  * to setCoefficients(stage, const int*).  sample_rate: the reference hard-codes
@@ -330,11 +336,16 @@ int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_chain **
  * n_samples = 128 reproduces the reference's block cadence and one call with a long block is the
  * same stream.  Q15 arithmetic needs n_samples even when biquad nodes are present. */
 int msdr_chain_process(msdr_chain *chain, const int16_t *d_if, void *d_audio, uint64_t n_samples);
-int msdr_chain_reset(msdr_chain *chain);                     /* init_FIR(): zero FIR + IIR state, phase 0 */
+/* init_FIR() (Minimal-SDR.ino:901-930: memset + arm_fir_init_q15 of both instances): zeroes the FIR state and nothing else --
+ * biquad / PLL / LMS state and the mixer's table position persist across a retune, as in the reference. */
+int msdr_chain_init_fir(msdr_chain *chain);
+/* stream restart (no counterpart in the reference): FIR state, fp32 cascade state, PLL and LMS state cleared, mixer phase 0.
+ * The Teensy biquad NODES of a Q15 chain keep their history (the reference never clears it, filter_biquad.cpp:95-97). */
+int msdr_chain_reset(msdr_chain *chain);
 int msdr_chain_set_mode(msdr_chain *chain, uint32_t channel, int32_t mode, int32_t tapset);
 /* Q15 chains: ANR_on per channel (host array of `channels` values, or NULL: anr_on_all for every channel); the LMS filter
  * then runs between the demodulator and the biquad nodes (Minimal-SDR.ino:702-770).  Its state is created on first use and
- * cleared by msdr_chain_reset(). */
+ * cleared by msdr_chain_reset() (not by msdr_chain_init_fir()). */
 int msdr_chain_set_anr(msdr_chain *chain, const int32_t *anr_on, int32_t anr_on_all);
 int msdr_chain_destroy(msdr_chain *chain);
 /* introspection for benchmarks/tests: name of the main kernel variant and launch geometry of the last call */

@@ -13,6 +13,7 @@
 #include "msdr_spectrum.hiph"
 #include "msdr_chain_q15mf.hiph"
 #include "msdr_fir_f32mf.hiph"
+#include "msdr_fir_f32tr.hiph"
 #include "msdr_design.h"
 
 #include <algorithm>
@@ -214,7 +215,12 @@ static int launch_check(const char *what)
 extern "C" void msdr_calc_FIR_coeffs(int16_t *coeffs, int numCoeffs, float32_t fc, float32_t Astop, int type, float dfc,
                                      float Fsamprate)
 {
-    msdr::design::calc_fir_coeffs(coeffs, numCoeffs, fc, Astop, type, dfc, Fsamprate);
+    msdr::design::calc_fir_coeffs(coeffs, numCoeffs, fc, Astop, type, dfc, Fsamprate, false);
+}
+extern "C" void msdr_calc_FIR_coeffs_pid(int16_t *coeffs, int numCoeffs, float32_t fc, float32_t Astop, int type, float dfc,
+                                         float Fsamprate)
+{
+    msdr::design::calc_fir_coeffs(coeffs, numCoeffs, fc, Astop, type, dfc, Fsamprate, true);
 }
 extern "C" int msdr_biquad_design(int kind, float frequency, float q_or_gain, float slope, double sample_rate, int32_t coef[5])
 {
@@ -474,6 +480,9 @@ struct msdr_fir_f32 : FirInst<float, float> {
     // matrix-core path (msdr_fir_f32mf.hiph): header + split-fp16 Toeplitz fragments, or null (then fir_kernel<FirF32> runs)
     char *d_fm_tab = nullptr;
     int fm_halo_ = 0, fm_bsteps = 0, fm_ex = 0;
+    // taps-in-registers path (msdr_fir_f32tr.hiph, <= ~290 taps): header + the two families of A fragments, or null
+    char *d_tr_tab = nullptr;
+    int tr_ns = 0, tr_skip1 = 0;
     float input_range = 0.0f;            // 0 = block floating point per tile (default); > 0: a fixed scale for samples below this magnitude
 };
 
@@ -624,6 +633,11 @@ static int fir_f32_upload_header(msdr_fir_f32 *S)
         h.fixed_k = std::max(-100, std::min(100, 15 - k));
     }
     HIP_TRY(hipMemcpyAsync(S->d_fm_tab, &h, sizeof h, hipMemcpyHostToDevice, S->ctx->stream));
+    if (S->d_tr_tab) {
+        F32TrHeader t;
+        t.ns = S->tr_ns; t.ex = S->fm_ex; t.fixed_k = h.fixed_k; t.use_fixed = h.use_fixed; t.skip1 = S->tr_skip1;
+        HIP_TRY(hipMemcpyAsync(S->d_tr_tab, &t, sizeof t, hipMemcpyHostToDevice, S->ctx->stream));
+    }
     HIP_TRY(hipStreamSynchronize(S->ctx->stream));
     return 0;
 }
@@ -654,6 +668,26 @@ extern "C" int msdr_fir_f32_create(msdr_ctx *ctx, uint16_t numTaps, const float3
                 }
         int rc = upload(ctx, blob, &S->d_fm_tab);
         S->fm_halo_ = H; S->fm_bsteps = ns; S->fm_ex = ex;
+        const int trs = tr_steps(N);
+        if (!rc && trs <= kTrMaxSteps && !getenv("MSDR_FIR_NO_TR")) {
+            // A fragments of v_mfma_f32_16x16x32_f16 (lane l: row a = l & 15, k = 8 (l >> 4) + j): T_F(s)[a][k'] = the tap at delay
+            // H + 16 F + a - k', k' = 32 s + 8 (l >> 4) + j; family F serves the sub-tiles a0 = 16 F and 32 + 16 F (one step later)
+            std::vector<char> tb(tr_table_bytes(trs), 0);
+            _Float16 *tf = reinterpret_cast<_Float16 *>(tb.data() + kTrHdrBytes);
+            for (int F = 0; F < 2; F++)
+                for (int st = 0; st < trs; st++)
+                    for (int l = 0; l < 64; l++)
+                        for (int jj = 0; jj < 8; jj++) {
+                            const int kk = 32 * st + 8 * (l >> 4) + jj, d = H + 16 * F + (l & 15) - kk;
+                            const double val = (d >= 0 && d < N) ? std::ldexp((double)pCoeffs[N - 1 - d], ex) : 0.0;
+                            const _Float16 vh = (_Float16)val;
+                            const size_t o = ((size_t)(F * trs + st) * 2) * 512 + l * 8 + jj;
+                            tf[o] = vh;
+                            tf[o + 512] = (_Float16)(val - (double)vh);
+                        }
+            rc = upload(ctx, tb, &S->d_tr_tab);
+            S->tr_ns = trs; S->tr_skip1 = (N <= H - 15) ? 1 : 0;
+        }
         if (!rc) rc = fir_f32_upload_header(S);
         if (rc) { msdr_fir_f32_destroy(S); *out = nullptr; return rc; }
     }
@@ -675,6 +709,30 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
     if (!d_src || !d_dst) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
     if ((const void *)d_src == (const void *)d_dst)
         return fail(MSDR_STATUS_ARGUMENT_ERROR, "FIR process is not in-place (the reference uses separate buffers, Minimal-SDR.ino:574-578)");
+    if (S->d_tr_tab) {
+        // taps in registers: 8 waves per CU; segments of >= 8 tiles, enough of them for four rounds of resident waves
+        const long long tiles = ((long long)blockSize + kTrTile - 1) / kTrTile;
+        long long nseg = (8192 + S->channels - 1) / S->channels;
+        nseg = std::max<long long>(1, std::min<long long>(nseg, std::max<long long>(1, tiles / 8)));
+        const long long seg_len = ((tiles + nseg - 1) / nseg) * kTrTile;
+        nseg = ((long long)blockSize + seg_len - 1) / seg_len;
+        const unsigned grid = (unsigned)(((long long)S->channels * nseg + 3) / 4);
+        const size_t lds = 4 * tr_wave_bytes(S->tr_ns);
+#define MSDR_TR_LAUNCH(NS_) case NS_: hipLaunchKernelGGL(fir_f32tr_kernel<NS_>, dim3(grid), dim3(256), lds, S->ctx->stream, d_src, d_dst, \
+            (const float *)S->d_hist[S->cur], (const char *)S->d_tr_tab, (long long)blockSize, (int)S->channels, (int)nseg, seg_len, (int)S->hist_len); break;
+        switch (S->tr_ns) {
+            MSDR_TR_LAUNCH(2) MSDR_TR_LAUNCH(3) MSDR_TR_LAUNCH(4) MSDR_TR_LAUNCH(5) MSDR_TR_LAUNCH(6)
+            MSDR_TR_LAUNCH(7) MSDR_TR_LAUNCH(8) MSDR_TR_LAUNCH(9) MSDR_TR_LAUNCH(10)
+            default: return fail(MSDR_STATUS_ARGUMENT_ERROR, "fir_f32tr: step count not built");
+        }
+#undef MSDR_TR_LAUNCH
+        if (int rc = launch_check("fir_f32tr_kernel")) return rc;
+        hipLaunchKernelGGL((history_kernel<float>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
+                           d_src, (const float *)S->d_hist[S->cur], S->d_hist[S->cur ^ 1], (long long)blockSize, (int)S->hist_len, (int)S->channels);
+        if (int rc = launch_check("history_kernel")) return rc;
+        S->cur ^= 1;
+        return 0;
+    }
     const int H = S->fm_halo_, ns = S->fm_bsteps;
     const long long tiles = ((long long)blockSize + kFmTile - 1) / kFmTile;
     long long nseg = (8192 + S->channels - 1) / S->channels;                       // two rounds of 16 waves per CU, >= two tiles per segment
@@ -698,7 +756,7 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
 extern "C" int msdr_fir_f32_reset(msdr_fir_f32 *S) { return fir_reset(S); }
 extern "C" int msdr_fir_f32_destroy(msdr_fir_f32 *S)
 {
-    if (S) hipFree(S->d_fm_tab);
+    if (S) { hipFree(S->d_fm_tab); hipFree(S->d_tr_tab); }
     return fir_destroy(S);
 }
 
@@ -932,7 +990,6 @@ static int freqconv_common(msdr_ctx *ctx, T *d_i, T *d_q, const T *osc_i, const 
     if (ctx->scratch_bytes < need) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->scratch) (void)hipFree(ctx->scratch);
-    if (ctx->d_fft_tables) (void)hipFree(ctx->d_fft_tables);
         ctx->scratch = nullptr; ctx->scratch_bytes = 0;
         HIP_TRY(hipMalloc(&ctx->scratch, std::max<size_t>(need, 4096)));
         ctx->scratch_bytes = std::max<size_t>(need, 4096);
@@ -2355,11 +2412,89 @@ extern "C" int msdr_chain_reset(msdr_chain *c)
     HIP_TRY(hipMemsetAsync(c->d_hist[1], 0, hb, c->ctx->stream));
     if (c->d_bq_state_alt) HIP_TRY(hipMemsetAsync(c->d_bq_state_alt, 0, (size_t)c->channels * kBqStateFloats * sizeof(float), c->ctx->stream));
     if (c->d_bq_state) HIP_TRY(hipMemsetAsync(c->d_bq_state, 0, (size_t)c->channels * kBqStateFloats * sizeof(float), c->ctx->stream));
-    // the reference never clears biquad history on retune (filter_biquad.cpp:95-97); init_FIR() only zeroes the FIR state.
+    // (a full clear for tests and stream restarts; the reference's init_FIR() is msdr_chain_init_fir(): FIR state only.  The
+    //  Teensy biquad NODES keep their history here too, as the reference never clears it: filter_biquad.cpp:95-97.)
     if (c->pll) if (int rc = msdr_syncam_reset(c->pll)) return rc;
     if (c->anr) if (int rc = msdr_anr_reset(c->anr)) return rc;
     if (c->seq_bq) if (int rc = msdr_biquad_df1_f32_reset(c->seq_bq)) return rc;
     c->phase = 0; c->gen++;
+    return 0;
+}
+
+// A mode whose matrix-core table folds the cascade's numerator C(z) into the FIR (msdr_chain_mfma.hiph): it neither maintains nor
+// reads the numerator history d[n-1-k] of the carried state.
+static bool chain_mode_folded(const msdr_chain *c, int m)
+{
+    return c->arith == MSDR_ARITH_F32 && c->mf_ok && c->nstages > 0 && (m == MSDR_MODE_LSB || m == MSDR_MODE_USB);
+}
+// d[-1-k], k < 8, of an SSB mode from a channel's raw IF history (what the folded FIR implies the cascade has seen)
+static void chain_ssb_history(const msdr_chain *c, const int16_t *hist, int m, int ts, double *D)
+{
+    const int N = (int)c->ntaps, HL = (int)c->hist_len, OL = (int)c->osc_len;
+    const float *hi = c->h_coef_i[ts].data(), *hq = c->h_coef_q[ts].data();
+    const double sign = (m == MSDR_MODE_LSB) ? -1.0 : 1.0;
+    for (int k = 0; k < 8; k++) {
+        double acc = 0.0;
+        for (int dl = 0; dl < N; dl++) {
+            const int t = -1 - k - dl, hx = HL + t;
+            if (hx < 0) break;
+            const int ph = (int)((((long long)c->phase + t) % OL + OL) % OL);
+            const double x = (double)hist[hx] * (double)c->in_scale;
+            acc += (double)hi[N - 1 - dl] * (x * c->h_osc[2 * ph]) + sign * (double)hq[N - 1 - dl] * (x * c->h_osc[2 * ph + 1]);
+        }
+        D[k] = acc;
+    }
+}
+// the numerator history as the cascade has really seen it: the cache (retuned again before any sample was processed), the folded
+// mode's own FIR over the raw history, or the state record
+static void chain_true_history(msdr_chain *c, uint32_t channel, const int16_t *hist, const float *st, double *D)
+{
+    if (c->dh_gen[channel] == c->gen) memcpy(D, c->dh_cache[channel].v, 8 * sizeof(double));
+    else if (chain_mode_folded(c, c->h_mode[channel])) chain_ssb_history(c, hist, c->h_mode[channel], c->h_tapset[channel], D);
+    else for (int k = 0; k < 8; k++) D[k] = st[k];
+    memcpy(c->dh_cache[channel].v, D, 8 * sizeof(double)); c->dh_gen[channel] = c->gen;
+}
+// first-sample corrections sum_k c[j+1+k] (D[k] - Dn[k]) of a folded mode whose FIR implies the history Dn
+static void chain_folded_correction(const msdr_chain *c, const double *D, const double *Dn, float *out)
+{
+    const int H2 = 2 * (int)c->nstages;
+    for (int j = 0; j < 8; j++) out[j] = 0.0f;
+    for (int j = 0; j < H2; j++) {
+        double a = 0.0;
+        for (int k = 0; j + 1 + k <= H2; k++) a += c->h_cnum[j + 1 + k] * (D[k] - Dn[k]);
+        out[j] = (float)a;
+    }
+}
+
+// init_FIR() (Minimal-SDR.ino:901-930) re-runs arm_fir_init_q15 and nothing else: the FIR state is zeroed; the biquad nodes, the
+// SYNCAM PLL statics (fil_out, omega2, phzerror) and the LMS weights / delay line persist across a retune, and so does the mixer's
+// position in its table.
+extern "C" int msdr_chain_init_fir(msdr_chain *c)
+{
+    if (!c) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null chain");
+    if (int rc = bind(c->ctx)) return rc;
+    bool any_folded = false;
+    for (uint32_t ch = 0; ch < c->channels && !any_folded; ch++) any_folded = chain_mode_folded(c, c->h_mode[ch]);
+    if (any_folded && c->d_bq_state) {
+        // a folded channel's numerator history lives in the raw IF history that is about to be cleared: hand it over as
+        // first-sample corrections, exactly as a retune does (msdr_chain_set_mode)
+        HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+        std::vector<int16_t> hist((size_t)c->channels * c->hist_len);
+        std::vector<float> st((size_t)c->channels * kBqStateFloats);
+        HIP_TRY(hipMemcpy(hist.data(), c->d_hist[c->cur], hist.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(st.data(), c->d_bq_state, st.size() * sizeof(float), hipMemcpyDeviceToHost));
+        const double zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t ch = 0; ch < c->channels; ch++) {
+            if (!chain_mode_folded(c, c->h_mode[ch])) continue;
+            double D[8];
+            chain_true_history(c, ch, hist.data() + (size_t)ch * c->hist_len, st.data() + (size_t)ch * kBqStateFloats, D);
+            chain_folded_correction(c, D, zero, st.data() + (size_t)ch * kBqStateFloats);
+        }
+        HIP_TRY(hipMemcpy(c->d_bq_state, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    const size_t hb = (size_t)c->channels * c->hist_len * sizeof(int16_t);
+    HIP_TRY(hipMemsetAsync(c->d_hist[0], 0, hb, c->ctx->stream));
+    HIP_TRY(hipMemsetAsync(c->d_hist[1], 0, hb, c->ctx->stream));
     return 0;
 }
 
@@ -2369,51 +2504,24 @@ extern "C" int msdr_chain_set_mode(msdr_chain *c, uint32_t channel, int32_t mode
     if (int rc = bind(c->ctx)) return rc;
     if (channel >= c->channels || mode < MSDR_MODE_SYNCAM || mode > MSDR_MODE_CW || tapset < 0 || (uint32_t)tapset >= c->tapsets)
         return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad channel/mode/tapset");
-    // The matrix-core kernel's SSB tables fold the cascade's numerator C(z) into the FIR (msdr_chain_mfma.hiph): such a mode
-    // neither maintains nor reads the numerator history d[n-1-k] of the carried state.  Keep the stream exact across a
-    // retune: D = the history as the cascade has really seen it (from the state, or rebuilt from the raw IF history with the
-    // old mode's taps); an unfolded new mode gets D; a folded one gets the correction sum_k c[j+1+k] (D[k] - D'[k]) to its
-    // first samples j, D' = the history its own FIR implies.
+    // Keep the stream exact across a retune when the old or the new mode's table folds the numerator into the FIR: D = the
+    // history as the cascade has really seen it; an unfolded new mode gets D; a folded one gets the correction
+    // sum_k c[j+1+k] (D[k] - D'[k]) to its first samples j, D' = the history its own FIR implies.
     {
         const int old_mode = c->h_mode[channel], old_ts = c->h_tapset[channel];
-        auto folded = [&](int m) { return c->arith == MSDR_ARITH_F32 && c->mf_ok && c->nstages > 0 && (m == MSDR_MODE_LSB || m == MSDR_MODE_USB); };
-        if ((folded(old_mode) || folded(mode)) && (old_mode != mode || old_ts != tapset)) {
+        if ((chain_mode_folded(c, old_mode) || chain_mode_folded(c, mode)) && (old_mode != mode || old_ts != tapset)) {
             HIP_TRY(hipStreamSynchronize(c->ctx->stream));
             std::vector<int16_t> hist(c->hist_len);
             float st[kBqStateFloats];
             HIP_TRY(hipMemcpy(hist.data(), c->d_hist[c->cur] + (size_t)channel * c->hist_len, hist.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(st, c->d_bq_state + (size_t)channel * kBqStateFloats, sizeof st, hipMemcpyDeviceToHost));
-            const int N = (int)c->ntaps, HL = (int)c->hist_len, OL = (int)c->osc_len;
-            auto ssb_history = [&](int m, int ts, double *D) {           // d[-1-k], k < 8, of an SSB mode from the raw history
-                const float *hi = c->h_coef_i[ts].data(), *hq = c->h_coef_q[ts].data();
-                const double sign = (m == MSDR_MODE_LSB) ? -1.0 : 1.0;
-                for (int k = 0; k < 8; k++) {
-                    double acc = 0.0;
-                    for (int dl = 0; dl < N; dl++) {
-                        const int t = -1 - k - dl, hx = HL + t;
-                        if (hx < 0) break;
-                        const int ph = (int)((((long long)c->phase + t) % OL + OL) % OL);
-                        const double x = (double)hist[hx] * (double)c->in_scale;
-                        acc += (double)hi[N - 1 - dl] * (x * c->h_osc[2 * ph]) + sign * (double)hq[N - 1 - dl] * (x * c->h_osc[2 * ph + 1]);
-                    }
-                    D[k] = acc;
-                }
-            };
             double D[8];
-            if (c->dh_gen[channel] == c->gen) memcpy(D, c->dh_cache[channel].v, sizeof D);      // retuned again before any sample was processed
-            else if (folded(old_mode)) ssb_history(old_mode, old_ts, D);
-            else for (int k = 0; k < 8; k++) D[k] = st[k];
-            memcpy(c->dh_cache[channel].v, D, sizeof D); c->dh_gen[channel] = c->gen;
+            chain_true_history(c, channel, hist.data(), st, D);
             float out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (folded(mode)) {
+            if (chain_mode_folded(c, mode)) {
                 double Dn[8];
-                ssb_history(mode, tapset, Dn);
-                const int H2 = 2 * (int)c->nstages;
-                for (int j = 0; j < H2; j++) {
-                    double a = 0.0;
-                    for (int k = 0; j + 1 + k <= H2; k++) a += c->h_cnum[j + 1 + k] * (D[k] - Dn[k]);
-                    out[j] = (float)a;
-                }
+                chain_ssb_history(c, hist.data(), mode, tapset, Dn);
+                chain_folded_correction(c, D, Dn, out);
             } else for (int k = 0; k < 8; k++) out[k] = (float)D[k];
             HIP_TRY(hipMemcpy(c->d_bq_state + (size_t)channel * kBqStateFloats, out, sizeof out, hipMemcpyHostToDevice));
         }

@@ -8,11 +8,17 @@ namespace msdr {
 namespace design {
 
 namespace {
-// `PI` as the vendored sources define it (src/CMSIS_5/arm_math.h:365-367, float fallback).
-constexpr float kPi = 3.14159265358979f;
-constexpr float kHalfPi = kPi / 2;
+// `PI` comes from outside the sketch.  Two sources exist: the vendored CMSIS header's float fallback (src/CMSIS_5/arm_math.h:365-367:
+// what the reference's files alone give) and, on the real target, Arduino.h's double literal, which wins there because it is
+// defined first.  With the double, `m * PIH`, `PIH * (float)(ii - nc / 2)` and `PIH * (2 * jj - nc) * fc` are evaluated in double
+// before they are rounded to float, and since the results are truncated to int16 single taps can differ by 1 LSB.  Both are
+// built (P = float / double), both are checked against the compiled reference (oracle/build_ref.sh: calc_FIR_coeffs / _pid).
+template <typename P> struct Pi;
+template <> struct Pi<float>  { static constexpr float half = 3.14159265358979f / 2; };
+template <> struct Pi<double> { static constexpr double half = 3.1415926535897932384626433832795 / 2; };
 
 inline int16_t to_q15(float v) { return (int16_t)(int32_t)v; }
+inline int16_t to_q15(double v) { return (int16_t)(int32_t)v; }
 
 // Kaiser window value at normalised position x in [-1,1)  (.ino:852-853)
 inline float kaiser(float beta, float x, float izb) { return izero(beta * sqrtf(1.0f - x * x)) / izb; }
@@ -43,14 +49,15 @@ float izero(float x)
 }
 
 // sin(m*pi/2*fc) / (m*pi/2*fc), m stepping by 2 (.ino:874-881)
-float sinc_half_pi(int m, float fc)
+template <typename P> static float sinc_half_pi_t(int m, float fc)
 {
     if (m == 0) return 1.0f;
-    const float x = m * kHalfPi;
+    const float x = (float)(m * Pi<P>::half);
     return sinf(x * fc) / (fc * x);
 }
+float sinc_half_pi(int m, float fc) { return sinc_half_pi_t<float>(m, fc); }
 
-void calc_fir_coeffs(int16_t *coeffs, int num_coeffs, float fc, float astop, int type, float dfc, float fsamp)
+template <typename P> static void calc_fir_coeffs_t(int16_t *coeffs, int num_coeffs, float fc, float astop, int type, float dfc, float fsamp)
 {
     fc = fc / fsamp;
     dfc = dfc / fsamp;
@@ -71,7 +78,7 @@ void calc_fir_coeffs(int16_t *coeffs, int num_coeffs, float fc, float astop, int
         for (int i = 1; i < nc + 1; i += 2) {
             if (2 * i == nc) continue;
             const float w = kaiser(beta, (float)(2 * i - nc) / (float)nc, izb);
-            coeffs[2 * i + 1] = to_q15(32767 * (1.0f / (kHalfPi * (float)(i - nc / 2)) * w));
+            coeffs[2 * i + 1] = to_q15(32767 * (1.0f / (Pi<P>::half * (float)(i - nc / 2)) * w));
         }
         return;
     }
@@ -80,15 +87,21 @@ void calc_fir_coeffs(int16_t *coeffs, int num_coeffs, float fc, float astop, int
     int j = 0;
     for (int i = -nc; i < nc; i += 2, j++) {                      // windowed sinc (.ino:850-855)
         const float w = kaiser(beta, (float)i / (float)nc, izb);
-        coeffs[j] = to_q15(fcf * sinc_half_pi(i, fcf) * w * 32767);
+        coeffs[j] = to_q15(fcf * sinc_half_pi_t<P>(i, fcf) * w * 32767);
     }
     if (type == 1) {
         coeffs[nc / 2] += 1;
     } else if (type == 2 || type == 3) {                          // modulate to the centre frequency (.ino:861-869)
         const float gain = (type == 2) ? 2.0f : -2.0f;
-        for (j = 0; j < nc + 1; j++) coeffs[j] = to_q15(coeffs[j] * (gain * cosf(kHalfPi * (2 * j - nc) * fc)));
+        for (j = 0; j < nc + 1; j++) coeffs[j] = to_q15(coeffs[j] * (gain * cosf((float)(Pi<P>::half * (2 * j - nc) * fc))));
         if (type == 3) coeffs[nc / 2] += 1;
     }
+}
+
+void calc_fir_coeffs(int16_t *coeffs, int num_coeffs, float fc, float astop, int type, float dfc, float fsamp, bool pi_double)
+{
+    if (pi_double) calc_fir_coeffs_t<double>(coeffs, num_coeffs, fc, astop, type, dfc, fsamp);
+    else calc_fir_coeffs_t<float>(coeffs, num_coeffs, fc, astop, type, dfc, fsamp);
 }
 
 void biquad_design(int kind, float frequency, float q_or_gain, float slope, double sample_rate, int32_t coef[5])

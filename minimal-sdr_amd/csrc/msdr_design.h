@@ -10,7 +10,7 @@ namespace design {
 
 float izero(float x);
 float sinc_half_pi(int m, float fc);
-void calc_fir_coeffs(int16_t *coeffs, int num_coeffs, float fc, float astop, int type, float dfc, float fsamp);
+void calc_fir_coeffs(int16_t *coeffs, int num_coeffs, float fc, float astop, int type, float dfc, float fsamp, bool pi_double = false);
 void fft128_tables(int16_t tables[352]);   // twiddleCoef_64_q15[96] | realCoefAQ15[::64 pairs][128] | realCoefBQ15[::64 pairs][128]
 void biquad_design(int kind, float frequency, float q_or_gain, float slope, double sample_rate, int32_t coef[5]);
 

@@ -251,7 +251,7 @@ public:
         if (cfg.arith != MSDR_ARITH_Q15 || cfg.channels != AudioGPU.channels()) return MSDR_STATUS_ARGUMENT_ERROR;
         return msdr_chain_create(AudioGPU.context(), &cfg, &chain);
     }
-    int init_FIR(void) { return chain ? msdr_chain_reset(chain) : MSDR_STATUS_ARGUMENT_ERROR; }     // Minimal-SDR.ino:901-930
+    int init_FIR(void) { return chain ? msdr_chain_init_fir(chain) : MSDR_STATUS_ARGUMENT_ERROR; }     // Minimal-SDR.ino:901-930
     int setMode(uint32_t channel, int mode, int tapset) { return chain ? msdr_chain_set_mode(chain, channel, mode, tapset) : MSDR_STATUS_ARGUMENT_ERROR; }
     virtual void update(void)
     {

@@ -70,6 +70,8 @@ def load_library(path=None):
         _lib.msdr_ctx_stream.restype = _p
         _lib.msdr_calc_FIR_coeffs.restype = None
         _lib.msdr_calc_FIR_coeffs.argtypes = [_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
+        _lib.msdr_calc_FIR_coeffs_pid.restype = None
+        _lib.msdr_calc_FIR_coeffs_pid.argtypes = [_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
         _lib.msdr_biquad_design.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_double, _p]
         _lib.msdr_biquad_df1_f32_cascade_info.argtypes = [C.c_uint8, _p, _p, _p, _p]
         _lib.msdr_malloc.argtypes = [_p, C.c_size_t, _p]
@@ -117,9 +119,12 @@ def _hp(a):
 
 
 # ---- host-side designers (no device needed) ---------------------------------------------------
-def calc_fir_coeffs(n, fc, astop=70.0, ftype=0, dfc=0.0, fs=24000.0, room=None):
+def calc_fir_coeffs(n, fc, astop=70.0, ftype=0, dfc=0.0, fs=24000.0, room=None, pi_double=False):
+    """pi_double: `PI` as Arduino.h's double literal (what a Teensy build sees) instead of the vendored header's float."""
     buf = np.zeros(room or (2 * n + 8), np.int16)
-    load_library().msdr_calc_FIR_coeffs(_hp(buf), int(n), float(fc), float(astop), int(ftype), float(dfc), float(fs))
+    lib = load_library()
+    f = lib.msdr_calc_FIR_coeffs_pid if pi_double else lib.msdr_calc_FIR_coeffs
+    f(_hp(buf), int(n), float(fc), float(astop), int(ftype), float(dfc), float(fs))
     return buf
 
 
@@ -534,6 +539,10 @@ class Chain(_Instance):
 
     def reset(self):
         _ck(self.ctx.lib.msdr_chain_reset(self.h))
+
+    def init_fir(self):
+        """init_FIR() (Minimal-SDR.ino:901-930): FIR state only."""
+        _ck(self.ctx.lib.msdr_chain_init_fir(self.h))
 
     def set_mode(self, channel, mode, tapset=0):
         _ck(self.ctx.lib.msdr_chain_set_mode(self.h, C.c_uint32(channel), C.c_int32(mode), C.c_int32(tapset)))

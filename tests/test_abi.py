@@ -51,11 +51,32 @@ def test_designer_fir_matches_golden(golden):
 
 def test_designer_fir_matches_oracle_random(orc):
     rng = np.random.default_rng(21)
+    differ = 0
     for _ in range(80):
         n = int(rng.integers(4, 520)) & ~1
         fc, a = float(rng.integers(100, 9000)), float(rng.choice([10.0, 30.0, 45.5, 50.0, 70.0, 90.0]))
-        t, dfc = int(rng.integers(0, 4)), float(rng.integers(50, 2000))
-        assert np.array_equal(msdr.calc_fir_coeffs(n, fc, a, t, dfc), orc.calc_fir_coeffs(n, fc, a, t, dfc))
+        t, dfc = int(rng.integers(0, 5)), float(rng.integers(50, 2000))
+        pif = msdr.calc_fir_coeffs(n, fc, a, t, dfc)
+        pid = msdr.calc_fir_coeffs(n, fc, a, t, dfc, pi_double=True)
+        assert np.array_equal(pif, orc.calc_fir_coeffs(n, fc, a, t, dfc))
+        assert np.array_equal(pid, orc.calc_fir_coeffs(n, fc, a, t, dfc, pi_double=True))
+        assert np.abs(pif.astype(np.int32) - pid).max() <= 2
+        differ += int(not np.array_equal(pif, pid))
+    assert differ > 0              # the two PIs are distinguishable: this test would notice a swapped flag
+
+
+def test_designer_fir_both_pi_variants_match_the_compiled_reference(ref):
+    """msdr_calc_FIR_coeffs = the sketch with the vendored header's float PI; msdr_calc_FIR_coeffs_pid = with Arduino.h's
+    double literal (what the Teensy binary computes).  Both against the reference's own source built with that PI."""
+    rng = np.random.default_rng(22)
+    for _ in range(60):
+        n = int(rng.integers(4, 520)) & ~1
+        fc, a = float(rng.integers(100, 9000)), float(rng.choice([20.0, 45.5, 70.0, 90.0]))
+        t, dfc = int(rng.integers(0, 5)), float(rng.integers(50, 2000))
+        for pid in (False, True):
+            want = ref.calc_fir_coeffs(n, fc, a, t, dfc, 24000.0, pi_double=pid)
+            got = msdr.calc_fir_coeffs(n, fc, a, t, dfc, 24000.0, room=want.size, pi_double=pid)
+            assert np.array_equal(got, want), (n, fc, a, t, dfc, pid)
 
 
 def test_designer_biquad_matches_oracle_and_survey(orc):

@@ -82,3 +82,31 @@ def test_show_spectrum_cadence_over_block_stream(ctx, orc):
     # counter: 0 -> draws at call 0, then 25; Spectrum_on == 0 skips the calls without counting (UI.cpp:533 returns first)
     assert drawn == [0, 25, 55]
     sp.close()
+
+
+def test_spectrum_tables_survive_freqconv_on_the_same_context(orc):
+    """The reference application runs freq_conv and the spectrum display side by side.  The first msdr_freqconv_* call of a
+    context grows its scratch buffer; that must not touch the FFT twiddle tables an earlier msdr_rfft128_q15 uploaded."""
+    own = msdr.Context(0)                                 # a fresh context: scratch_bytes starts at 0
+    try:
+        rng = np.random.default_rng(5)
+        x = rng.integers(-20000, 20001, (64, 128)).astype(np.int16)
+        before, colb = _run(own, x)
+        n = np.arange(128)
+        oi = np.round(32767 * np.sin(2 * np.pi * 5 * n / 128)).astype(np.int16)
+        oq = np.round(32767 * np.cos(2 * np.pi * 5 * n / 128)).astype(np.int16)
+        i0 = rng.integers(-30000, 30001, (8, 128)).astype(np.int16)
+        q0 = np.zeros_like(i0)
+        di, dq = own.to_device(i0), own.to_device(q0)
+        own.freqconv_q15(di, dq, oi, oq, 1, 1, 8, 128)
+        gi, gq = di.download(), dq.download()
+        for c in range(8):
+            wi, wq = orc.freqconv_q15(i0[c], q0[c], oi, oq, 1, 1)
+            assert np.array_equal(gi[c], wi) and np.array_equal(gq[c], wq)
+        after, cola = _run(own, x)
+        assert np.array_equal(before, after) and np.array_equal(colb, cola)
+        for f in range(0, 64, 9):
+            want, _ = orc.rfft128_q15(x[f])
+            assert np.array_equal(after[f], want)
+    finally:
+        own.close()

@@ -371,3 +371,25 @@ def test_biquad_df1_f32_cmsis_order_long_stream_of_few_channels(ctx, orc, ch, sp
         assert rel_rms(got[c, tail], want[tail]) < 1e-5, (spec, c, rel_rms(got[c, tail], want[tail]))
         # inside a later call and across its segment borders the two agree sample by sample to the cascade's own fp32 noise
         assert np.abs(got[c, tail] - want[tail]).max() < 1e-4 * np.abs(want[tail]).max() + 1e-6, (spec, c)
+
+
+@pytest.mark.parametrize("ntaps", [16, 17, 33, 48, 49, 64, 65, 97, 113, 128, 129, 161, 193, 225, 242, 257, 289, 290, 321])
+def test_fir_f32_taps_in_registers_every_step_count(ctx, orc, ntaps):
+    """msdr_fir_f32tr.hiph: one instantiation per number of 32-sample k-steps (2 .. 10: 16 .. 289 taps; longer filters stay on
+    msdr_fir_f32mf.hiph).  Tap counts on both sides of every boundary, with and without the all-zero first step of the second
+    fragment family; many channels, time segments, a ragged second call, asymmetric taps (a mirrored table would show)."""
+    rng = np.random.default_rng(ntaps)
+    ch, n1, n2 = 37, 11 * 1024, 5 * 1024 + 333
+    h = (rng.standard_normal(ntaps) * np.linspace(1.0, 0.2, ntaps)).astype(np.float32)
+    x = (rng.uniform(-1, 1, (ch, n1 + n2)) * 5000.0).astype(np.float32)
+    fir = msdr.FirF32(ctx, h, ch)
+    got = np.empty_like(x)
+    for o, m in ((0, n1), (n1, n2)):
+        dx, dy = ctx.to_device(x[:, o:o + m]), ctx.array((ch, m), np.float32)
+        fir.process(dx, dy, m)
+        got[:, o:o + m] = dy.download()
+    for c in (0, 1, 18, ch - 1):
+        truth = np.convolve(x[c].astype(np.float64), h[::-1].astype(np.float64))[:n1 + n2]      # arm_fir_f32 keeps its taps time-reversed
+        assert rel_rms(got[c], truth) < 1e-6, (ntaps, c, rel_rms(got[c], truth))
+    want = orc.fir_f32_blocks(h, x[5, :(n1 + n2) // 128 * 128], 128)
+    assert rel_rms(got[5, :want.size], want) < 1e-6

@@ -87,6 +87,11 @@ int  msdr_device_count(void);                               /* usable gfx950 dev
 int msdr_malloc(msdr_ctx *ctx, size_t bytes, void **d_ptr);
 int msdr_free(msdr_ctx *ctx, void *d_ptr);
 int msdr_memcpy_h2d(msdr_ctx *ctx, void *d_dst, const void *src, size_t bytes);   /* stream-ordered, returns after the copy */
+/* Optional: HIP events on the context's stream around the MAIN kernel of each msdr_fir_q15_process / msdr_fir_f32_process call
+ * (not its history kernel), for roofline arithmetic; msdr_ctx_get_kernel_time synchronises the stream and returns the sum of
+ * the durations and the number of launches since the last reset.  (The fused chain has its own pair: msdr_chain_enable_timing.) */
+int msdr_ctx_enable_kernel_timing(msdr_ctx *ctx, int on);
+int msdr_ctx_get_kernel_time(msdr_ctx *ctx, double *total_ms, uint64_t *launches, int reset);
 int msdr_memcpy_d2h(msdr_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 int msdr_memcpy_d2d(msdr_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);     /* stream-ordered, asynchronous */
 int msdr_memset(msdr_ctx *ctx, void *d_dst, int value, size_t bytes);

@@ -66,6 +66,30 @@ struct msdr_ctx {
     void *scratch;          // small device buffer reused for per-call host tables (oscillator tables)
     size_t scratch_bytes;
     int16_t *d_fft_tables;  // twiddle / split tables of the 128-point q15 real FFT, created on first use
+    // msdr_ctx_enable_kernel_timing: HIP events on `stream` around the MAIN kernel of the stage mirrors (msdr_fir_*_process)
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double timed_ms = 0.0;
+    uint64_t timed_launches = 0;
+};
+
+// brackets one kernel launch with events when the context's timing is on (at most 8192 pending pairs)
+struct KernelTimer {
+    msdr_ctx *ctx;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    explicit KernelTimer(msdr_ctx *c) : ctx(c)
+    {
+        if (!c->timing || c->events.size() >= 8192) return;
+        if (hipEventCreate(&e0) != hipSuccess) { e0 = nullptr; return; }
+        if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); e0 = e1 = nullptr; return; }
+        if (hipEventRecord(e0, c->stream) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); e0 = e1 = nullptr; }
+    }
+    ~KernelTimer()
+    {
+        if (!e0) return;
+        if (hipEventRecord(e1, ctx->stream) == hipSuccess) ctx->events.emplace_back(e0, e1);
+        else { hipEventDestroy(e0); hipEventDestroy(e1); }
+    }
 };
 
 static int bind(msdr_ctx *ctx)
@@ -122,8 +146,32 @@ extern "C" int msdr_ctx_destroy(msdr_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_fft_tables) (void)hipFree(ctx->d_fft_tables);
+    for (auto &e : ctx->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return 0;
+}
+
+extern "C" int msdr_ctx_enable_kernel_timing(msdr_ctx *ctx, int on)
+{
+    if (!ctx) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null context");
+    ctx->timing = on != 0;
+    return 0;
+}
+extern "C" int msdr_ctx_get_kernel_time(msdr_ctx *ctx, double *total_ms, uint64_t *launches, int reset)
+{
+    if (int rc = bind(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (auto &e : ctx->events) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+        ctx->timed_ms += ms; ctx->timed_launches++;
+        hipEventDestroy(e.first); hipEventDestroy(e.second);
+    }
+    ctx->events.clear();
+    if (total_ms) *total_ms = ctx->timed_ms;
+    if (launches) *launches = ctx->timed_launches;
+    if (reset) { ctx->timed_ms = 0; ctx->timed_launches = 0; }
     return 0;
 }
 
@@ -529,7 +577,7 @@ static int fir_process(Inst *S, const In *d_src, In *d_dst, uint32_t blockSize)
     p.seg_len = seg_tiles * kFirTile;
     p.nseg = (int)((tiles + seg_tiles - 1) / seg_tiles);
     p.ntaps_pad = (int)S->ntaps_pad; p.hist_len = (int)S->hist_len; p.taps = S->d_taps;
-    hipLaunchKernelGGL((fir_kernel<F>), dim3(S->channels * p.nseg), dim3(kThreads), fir_lds_bytes(p.ntaps_pad), S->ctx->stream, p);
+    { KernelTimer kt(S->ctx); hipLaunchKernelGGL((fir_kernel<F>), dim3(S->channels * p.nseg), dim3(kThreads), fir_lds_bytes(p.ntaps_pad), S->ctx->stream, p); }
     if (int rc = launch_check("fir_kernel")) return rc;
     hipLaunchKernelGGL((history_kernel<In>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
                        d_src, (const In *)S->d_hist[S->cur], S->d_hist[S->cur ^ 1], (long long)blockSize, (int)S->hist_len,
@@ -606,7 +654,7 @@ extern "C" int msdr_fir_q15_process(msdr_fir_q15 *S, const q15_t *d_src, q15_t *
     while (nw > 1 && qm_lds_bytes(S->qm_halo, S->qm_bsteps, nw) > 80 * 1024) nw >>= 1;
     q.mf_nw = nw; q.nseg = (int)qseg; q.seg_len = qseg_len; q.fold_period = 0; q.fold_rot = (int)S->channels; q.mf_waves = 0;
     const unsigned grid = (unsigned)(((long long)S->channels * qseg + nw - 1) / nw);
-    hipLaunchKernelGGL(chain_q15mf_kernel<3>, dim3(grid), dim3(nw * 64), qm_lds_bytes(S->qm_halo, S->qm_bsteps, nw), S->ctx->stream, q);
+    { KernelTimer kt(S->ctx); hipLaunchKernelGGL(chain_q15mf_kernel<3>, dim3(grid), dim3(nw * 64), qm_lds_bytes(S->qm_halo, S->qm_bsteps, nw), S->ctx->stream, q); }
     if (int rc = launch_check("chain_q15mf_kernel<3>")) return rc;
     hipLaunchKernelGGL((history_kernel<int16_t>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
                        d_src, (const int16_t *)S->d_hist[S->cur], S->d_hist[S->cur ^ 1], (long long)blockSize, (int)S->hist_len, (int)S->channels);
@@ -718,13 +766,18 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
         nseg = ((long long)blockSize + seg_len - 1) / seg_len;
         const unsigned grid = (unsigned)(((long long)S->channels * nseg + 3) / 4);
         const size_t lds = 4 * tr_wave_bytes(S->tr_ns);
-#define MSDR_TR_LAUNCH(NS_) case NS_: hipLaunchKernelGGL(fir_f32tr_kernel<NS_>, dim3(grid), dim3(256), lds, S->ctx->stream, d_src, d_dst, \
-            (const float *)S->d_hist[S->cur], (const char *)S->d_tr_tab, (long long)blockSize, (int)S->channels, (int)nseg, seg_len, (int)S->hist_len); break;
+#define MSDR_TR_LAUNCH(NS_) case NS_: \
+            if (S->tr_skip1) hipLaunchKernelGGL((fir_f32tr_kernel<NS_, true>), dim3(grid), dim3(256), lds, S->ctx->stream, d_src, d_dst, \
+                (const float *)S->d_hist[S->cur], (const char *)S->d_tr_tab, (long long)blockSize, (int)S->channels, (int)nseg, seg_len, (int)S->hist_len); \
+            else hipLaunchKernelGGL((fir_f32tr_kernel<NS_, false>), dim3(grid), dim3(256), lds, S->ctx->stream, d_src, d_dst, \
+                (const float *)S->d_hist[S->cur], (const char *)S->d_tr_tab, (long long)blockSize, (int)S->channels, (int)nseg, seg_len, (int)S->hist_len); \
+            break;
+        { KernelTimer kt(S->ctx);
         switch (S->tr_ns) {
             MSDR_TR_LAUNCH(2) MSDR_TR_LAUNCH(3) MSDR_TR_LAUNCH(4) MSDR_TR_LAUNCH(5) MSDR_TR_LAUNCH(6)
             MSDR_TR_LAUNCH(7) MSDR_TR_LAUNCH(8) MSDR_TR_LAUNCH(9) MSDR_TR_LAUNCH(10)
             default: return fail(MSDR_STATUS_ARGUMENT_ERROR, "fir_f32tr: step count not built");
-        }
+        } }
 #undef MSDR_TR_LAUNCH
         if (int rc = launch_check("fir_f32tr_kernel")) return rc;
         hipLaunchKernelGGL((history_kernel<float>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
@@ -741,11 +794,11 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
     nseg = ((long long)blockSize + seg_len - 1) / seg_len;
     int nw = 16;
     while (nw > 1 && ((long long)S->channels * nseg < 256LL * nw || fm_lds_bytes(H, ns, nw) > 160 * 1024)) nw >>= 1;
-    if (const char *e = getenv("MSDR_FM_NW")) nw = std::max(1, std::min(16, atoi(e)));           // experiment: waves per workgroup
     const unsigned grid = (unsigned)(((long long)S->channels * nseg + nw - 1) / nw);
-    hipLaunchKernelGGL(fir_f32mf_kernel, dim3(grid), dim3(nw * 64), fm_lds_bytes(H, ns, nw), S->ctx->stream, d_src, d_dst,
+    { KernelTimer kt(S->ctx);
+      hipLaunchKernelGGL(fir_f32mf_kernel, dim3(grid), dim3(nw * 64), fm_lds_bytes(H, ns, nw), S->ctx->stream, d_src, d_dst,
                        (const float *)S->d_hist[S->cur], (const char *)S->d_fm_tab, (long long)blockSize, (int)S->channels, (int)nseg, seg_len,
-                       (int)S->hist_len, H, ns, nw);
+                       (int)S->hist_len, H, ns, nw); }
     if (int rc = launch_check("fir_f32mf_kernel")) return rc;
     hipLaunchKernelGGL((history_kernel<float>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
                        d_src, (const float *)S->d_hist[S->cur], S->d_hist[S->cur ^ 1], (long long)blockSize, (int)S->hist_len, (int)S->channels);
@@ -1406,6 +1459,7 @@ struct msdr_chain {
     float *d_fft_h, *d_fft_tw;
     void *d_bq_fft;
     // matrix-core path (msdr_chain_mfma.hiph): any short-period oscillator, any mode
+    bool no_biquad_pipe;                                  // MSDR_NO_BIQUAD_PIPE, read once at creation (A/B switch for the two-wave node pipeline)
     bool mf_ok;
     int mf_halo, mf_bsteps, mf_stride;
     char *d_mf_tab;
@@ -1535,6 +1589,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->pole_radius = c->nstages ? max_pole_radius(cfg->biquad_coeffs, (int)c->nstages) : 0.0;
     c->cur = 0; c->phase = 0; c->timing = false; c->timed_ms = 0; c->timed_launches = 0;
     c->gen = 1; c->dh_cache.resize(c->channels); c->dh_gen.assign(c->channels, 0);
+    c->no_biquad_pipe = getenv("MSDR_NO_BIQUAD_PIPE") != nullptr;
     c->flags = cfg->flags; c->mfw_nw = 0; c->mfw_waves_per_cu = 0; c->d_bq_state_alt = nullptr; c->d_mw_iir = nullptr; c->d_units = nullptr; c->units_cap = 0;
     c->mode_gen = 1; c->units_mode_gen = 0; c->units_nseg = 0; c->units_wgs = 0; c->units_wgs_ssb = 0; c->mfw_ssb_fold = false; c->mfw_am_fold = false; c->units_tiles = -1;
     c->part_nseg[0] = c->part_nseg[1] = 1; c->part_seg_len[0] = c->part_seg_len[1] = 0;
@@ -2246,8 +2301,8 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         p.warm = (int)(nseg > 1 ? warm_tiles * kTile : 0);
         grid = c->units_wgs;
         p.mf_units = c->d_units; p.mf_nw = nw; p.bq_state_out = c->d_bq_state_alt; p.mw_iir = c->d_mw_iir;
-        { const char *e = getenv("MSDR_DBG"); p.dbg = e ? atoi(e) : 0; }
 #ifdef MSDR_STAMPS
+        { const char *e = getenv("MSDR_DBG"); p.dbg = e ? atoi(e) : 0; }
         static unsigned long long *stamp_buf = nullptr;
         const size_t stamp_n = (size_t)grid * nw * 8;
         if (!stamp_buf) HIP_TRY(hipMalloc(&stamp_buf, (1u << 20) * 8 * sizeof(unsigned long long)));
@@ -2377,7 +2432,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         if (int rc = msdr_anr_q15(c->anr, c->d_anr_on, c->anr_all, (q15_t *)d_audio, (uint32_t)n_samples)) return rc;
 
     if (c->nnodes == 2) {      // biquad1_dac -> biquad2_dac in one pass over the audio
-        if ((c->channels & 63u) == 0 && (n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 && !getenv("MSDR_NO_BIQUAD_PIPE"))
+        if ((c->channels & 63u) == 0 && (n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 && !c->no_biquad_pipe)
             hipLaunchKernelGGL(biquad_teensy_pipe_kernel, dim3(c->channels / 64), dim3(128), 0, c->ctx->stream, (short *)d_audio,
                                c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);     // node per wave, slab pipeline
         else

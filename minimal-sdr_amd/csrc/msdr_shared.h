@@ -95,7 +95,7 @@ struct ChainParams {
     const int *mf_units;       // [workgroups][mf_nw] pairs (channel, segment); channel < 0 = idle wave
     int mf_nw;                 // waves per workgroup (1..16)
     unsigned long long *dbg_buf;   // diagnostic build (-DMSDR_STAMPS): per-phase cycle sums, 8 per unit
-    int dbg;                   // diagnostic bits (MSDR_DBG environment variable; 0 in normal operation)
+    int dbg;                   // diagnostic bits: read from MSDR_DBG by the -DMSDR_STAMPS build only; the product build never looks at it
     const float *mw_iir;       // wave-stream kernel, folded IIR: MwIirConsts block (scan matrices, response fragments), or null
     float *bq_state_out;       // [channels][kBqStateFloats] cascade state after this call (ping-pong partner of bq_state)
 };

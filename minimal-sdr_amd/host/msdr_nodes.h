@@ -7,6 +7,7 @@
 // plus AudioSDRDemodulator, the fused node (one kernel for demodulation() + the biquad nodes behind it).
 // Every block is a block batch in HBM (AudioStream.h); update() enqueues kernels, never touches samples.
 #pragma once
+#include <atomic>
 #include <vector>
 
 #include "AudioStream.h"
@@ -134,106 +135,108 @@ private:
 };
 
 // ------------------------------------------------------------------------------------------------
-// AudioRecordQueue -- hands graph blocks to the main loop (record_queue.h:34-58, record_queue.cpp:31-97).
+// BlockRing -- a single-producer / single-consumer ring of block pointers.  One side is the graph tick (update(), the software
+// interrupt of the reference), the other the main loop; each side owns one free-running counter, so neither ever writes what
+// the other one writes and a full ring is told from an empty one without giving up a slot.
+// ------------------------------------------------------------------------------------------------
+template <unsigned CAPACITY>
+class BlockRing {
+public:
+    unsigned size(void) const { return pushed.load(std::memory_order_acquire) - popped.load(std::memory_order_acquire); }
+    bool push(audio_block_t *block)                   // producer side; false = full
+    {
+        const unsigned w = pushed.load(std::memory_order_relaxed);
+        if (w - popped.load(std::memory_order_acquire) >= CAPACITY) return false;
+        slot[w % CAPACITY] = block;
+        pushed.store(w + 1, std::memory_order_release);
+        return true;
+    }
+    audio_block_t *pop(void)                          // consumer side; NULL = empty
+    {
+        const unsigned r = popped.load(std::memory_order_relaxed);
+        if (r == pushed.load(std::memory_order_acquire)) return nullptr;
+        audio_block_t *block = slot[r % CAPACITY];
+        popped.store(r + 1, std::memory_order_release);
+        return block;
+    }
+
+private:
+    audio_block_t *slot[CAPACITY];
+    std::atomic<unsigned> pushed{0}, popped{0};
+};
+
+// ------------------------------------------------------------------------------------------------
+// AudioRecordQueue -- hands graph blocks to the main loop (interface of record_queue.h:34-58; the reference keeps 53 slots of which
+// 52 can be occupied, and drops the incoming block when they are: record_queue.cpp:91-92).
 // readBuffer() returns a DEVICE pointer to [channels][128] int16.
 // ------------------------------------------------------------------------------------------------
 class AudioRecordQueue : public AudioStream {
 public:
-    AudioRecordQueue(void) : AudioStream(1, inputQueueArray), userblock(nullptr), head(0), tail(0), enabled(0) {}
-    void begin(void) { clear(); enabled = 1; }
-    int available(void)
-    {
-        uint32_t h = head, t = tail;
-        return (h >= t) ? (int)(h - t) : (int)(kSlots + h - t);
-    }
+    AudioRecordQueue(void) : AudioStream(1, inputQueueArray), lent(nullptr), recording(false) {}
+    void begin(void) { clear(); recording.store(true); }
+    void end(void) { recording.store(false); }
+    int available(void) { return (int)ring.size(); }
     void clear(void)
     {
-        if (userblock) { release(userblock); userblock = nullptr; }
-        uint32_t t = tail;
-        while (t != head) { if (++t >= kSlots) t = 0; release(queue[t]); }
-        tail = t;
+        freeBuffer();
+        while (audio_block_t *b = ring.pop()) release(b);
     }
-    int16_t *readBuffer(void)
+    int16_t *readBuffer(void)                         // one block at a time is out with the main loop
     {
-        if (userblock) return nullptr;
-        uint32_t t = tail;
-        if (t == head) return nullptr;
-        if (++t >= kSlots) t = 0;
-        userblock = queue[t];
-        tail = t;
-        return userblock->data;
+        if (lent) return nullptr;
+        lent = ring.pop();
+        return lent ? lent->data : nullptr;
     }
     void freeBuffer(void)
     {
-        if (userblock == nullptr) return;
-        release(userblock);
-        userblock = nullptr;
+        if (lent) release(lent);
+        lent = nullptr;
     }
-    void end(void) { enabled = 0; }
     virtual void update(void)
     {
         audio_block_t *block = receiveReadOnly();
         if (!block) return;
-        if (!enabled) { release(block); return; }
-        uint32_t h = head + 1;
-        if (h >= kSlots) h = 0;
-        if (h == tail) release(block);             // ring full: the block is dropped (record_queue.cpp:91-92)
-        else { queue[h] = block; head = h; }
+        if (!recording.load() || !ring.push(block)) release(block);
     }
 
 private:
-    static const uint32_t kSlots = 53;             // record_queue.h:52
     audio_block_t *inputQueueArray[1];
-    audio_block_t *volatile queue[kSlots];
-    audio_block_t *userblock;
-    volatile uint32_t head, tail, enabled;
+    BlockRing<52> ring;
+    audio_block_t *lent;
+    std::atomic<bool> recording;
 };
 
 // ------------------------------------------------------------------------------------------------
-// AudioPlayQueue -- main loop feeds blocks into the graph (play_queue.h:34-52, play_queue.cpp:31-75).
+// AudioPlayQueue -- main loop feeds blocks into the graph (interface of play_queue.h:34-52; 32 slots of which 31 can be occupied).
+// Where the reference busy-waits (allocate() in getBuffer, a full ring in playBuffer: play_queue.cpp:42-46, :56) these return
+// NULL / false: there is no interrupt here that could end the wait.
 // ------------------------------------------------------------------------------------------------
 class AudioPlayQueue : public AudioStream {
 public:
-    AudioPlayQueue(void) : AudioStream(0, nullptr), userblock(nullptr), head(0), tail(0) {}
-    bool available(void)
+    AudioPlayQueue(void) : AudioStream(0, nullptr), filling(nullptr) {}
+    bool available(void) { return getBuffer() != nullptr; }
+    int16_t *getBuffer(void)
     {
-        if (userblock) return true;
-        userblock = allocate();
-        return userblock != nullptr;
+        if (!filling) filling = allocate();
+        return filling ? filling->data : nullptr;
     }
-    int16_t *getBuffer(void)                         // the reference spins on allocate(); here: NULL when the pool is empty
+    bool playBuffer(void)
     {
-        if (userblock) return userblock->data;
-        userblock = allocate();
-        return userblock ? userblock->data : nullptr;
-    }
-    bool playBuffer(void)                            // false when the 32-slot ring is full (the reference busy-waits, play_queue.cpp:56)
-    {
-        if (!userblock) return false;
-        uint32_t h = head + 1;
-        if (h >= kSlots) h = 0;
-        if (tail == h) return false;
-        queue[h] = userblock;
-        head = h;
-        userblock = nullptr;
+        if (!filling || !ring.push(filling)) return false;
+        filling = nullptr;
         return true;
     }
     virtual void update(void)
     {
-        uint32_t t = tail;
-        if (t == head) return;
-        if (++t >= kSlots) t = 0;
-        audio_block_t *block = queue[t];
-        tail = t;
-        transmit(block);
-        release(block);
+        if (audio_block_t *block = ring.pop()) {
+            transmit(block);
+            release(block);
+        }
     }
 
 private:
-    static const uint32_t kSlots = 32;              // play_queue.h:47
-    audio_block_t *volatile queue[kSlots];
-    audio_block_t *userblock;
-    volatile uint32_t head, tail;
+    BlockRing<31> ring;
+    audio_block_t *filling;
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -209,6 +209,15 @@ class Context:
         return DeviceArray(self, a.shape, a.dtype).upload(a)
 
     # ---- stateless stages -----------------------------------------------------------------------
+    def enable_kernel_timing(self, on=True):
+        """HIP events around the main kernel of the FIR stage mirrors (msdr_ctx_enable_kernel_timing)."""
+        _ck(self.lib.msdr_ctx_enable_kernel_timing(self.h, int(on)))
+
+    def kernel_time(self, reset=True):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        _ck(self.lib.msdr_ctx_get_kernel_time(self.h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
     def mix_fs4_q15(self, d_x, d_i, d_q, channels, n):
         _ck(self.lib.msdr_mix_fs4_q15(self.h, _p(d_x.ptr), _p(d_i.ptr), _p(d_q.ptr), C.c_uint32(channels), C.c_uint32(n)))
 

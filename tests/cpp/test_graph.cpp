@@ -109,10 +109,30 @@ static void fetch(AudioRecordQueue &q, std::vector<int16_t> &out)
 int main(int argc, char **argv)
 {
     if (argc > 1 && !strcmp(argv[1], "--no-gpu")) {
+        {   // the queue nodes' ring (host logic only): order, capacity, wrap-around, full / empty
+            BlockRing<3> ring;
+            audio_block_t blk[5];
+            CHECK(ring.size() == 0 && ring.pop() == nullptr, "a new ring is empty");
+            CHECK(ring.push(&blk[0]) && ring.push(&blk[1]) && ring.push(&blk[2]), "three blocks fit");
+            CHECK(!ring.push(&blk[3]) && ring.size() == 3, "the fourth is refused and nothing changes");
+            CHECK(ring.pop() == &blk[0] && ring.pop() == &blk[1] && ring.size() == 1, "first in, first out");
+            for (int round = 0; round < 1000; round++) {                     // many laps around the three slots
+                CHECK(ring.push(&blk[round % 5]), "push lap %d", round);
+                CHECK(ring.pop() == &blk[round ? (round - 1) % 5 : 2], "pop lap %d", round);
+            }
+            CHECK(ring.size() == 1 && ring.pop() == &blk[999 % 5] && ring.pop() == nullptr, "drained");
+        }
         int rc = AudioGPU.begin(0, CH);
         if (msdr_device_count() == 0) {
             CHECK(rc == MSDR_STATUS_NO_DEVICE, "begin() without a GPU returned %d", rc);
             CHECK(AudioMemory(20) != 0, "AudioMemory must fail without a context");
+            // without a pool the queues hand out nothing and accept nothing, and never spin
+            AudioPlayQueue pq;
+            AudioRecordQueue rq;
+            CHECK(!pq.available() && pq.getBuffer() == nullptr && !pq.playBuffer(), "play queue without a pool");
+            rq.begin();
+            CHECK(rq.available() == 0 && rq.readBuffer() == nullptr, "record queue without data");
+            rq.freeBuffer(); rq.clear(); rq.end();
             printf("no-gpu path: %s (%s)\n", fails ? "FAILED" : "OK", msdr_last_error());
         }
         return fails ? 1 : 0;

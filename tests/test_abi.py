@@ -52,17 +52,20 @@ def test_designer_fir_matches_golden(golden):
 def test_designer_fir_matches_oracle_random(orc):
     rng = np.random.default_rng(21)
     differ = 0
+    # three designs where the two PIs give different taps (about 1.4 % of random designs do: 1 LSB in a tap pair), then random ones
+    cases = [(504, 7945.0, 70.0, 0, 1592.0), (206, 8477.0, 30.0, 0, 1690.0), (250, 7163.0, 10.0, 1, 483.0)]
     for _ in range(80):
         n = int(rng.integers(4, 520)) & ~1
         fc, a = float(rng.integers(100, 9000)), float(rng.choice([10.0, 30.0, 45.5, 50.0, 70.0, 90.0]))
-        t, dfc = int(rng.integers(0, 5)), float(rng.integers(50, 2000))
+        cases.append((n, fc, a, int(rng.integers(0, 5)), float(rng.integers(50, 2000))))
+    for n, fc, a, t, dfc in cases:
         pif = msdr.calc_fir_coeffs(n, fc, a, t, dfc)
         pid = msdr.calc_fir_coeffs(n, fc, a, t, dfc, pi_double=True)
         assert np.array_equal(pif, orc.calc_fir_coeffs(n, fc, a, t, dfc))
         assert np.array_equal(pid, orc.calc_fir_coeffs(n, fc, a, t, dfc, pi_double=True))
         assert np.abs(pif.astype(np.int32) - pid).max() <= 2
         differ += int(not np.array_equal(pif, pid))
-    assert differ > 0              # the two PIs are distinguishable: this test would notice a swapped flag
+    assert differ >= 3             # the two PIs are distinguishable: this test would notice a swapped flag
 
 
 def test_designer_fir_both_pi_variants_match_the_compiled_reference(ref):

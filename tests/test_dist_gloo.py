@@ -37,9 +37,48 @@ def _worker(rank, world, port, total, n, q):
     local = np.stack([orc.chain_q15(x_all[c], modes[c], taps, taps) for c in range(start, start + count)]) if count else np.zeros((0, n), np.int16)
     full = msdr_dist.gather_audio(torch.from_numpy(local), total)
     slowest = msdr_dist.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    # gather to one rank only (the play-out host): root 1 here, so that rank 0 is a pure sender
+    at_root = msdr_dist.gather_audio_root(torch.from_numpy(local), total, root=1)
+    root_ok = torch.tensor([1.0 if (at_root is None) == (rank != 1) else 0.0])
+    if rank == 1:
+        root_ok[0] = float(torch.equal(at_root, full))
+    dist.all_reduce(root_ok, op=dist.ReduceOp.MIN)
+    # double-buffered schedule: block k is gathered while block k + 1 is demodulated; fp32 audio this time (4-byte samples)
+    blocks, nb = 5, n // 2
+    state = [dict() for _ in range(count)]
+    og = msdr_dist.OverlappedGather(total, count, nb, torch.float32, torch.device("cpu"), root=0)
+    og_all = msdr_dist.OverlappedGather(total, count, nb, torch.float32, torch.device("cpu"), root=None)
+    cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+    hf = taps.astype(np.float32) / 32768.0
+    got_blocks = []
+    for k in range(blocks):
+        buf, buf2 = og.buffer(k), og_all.buffer(k)
+        if k >= 2 and rank == 0:
+            got_blocks.append(og.result(k).clone())          # block k - 2, complete by now (buffer() waited for it)
+        xb = x_all[start:start + count, (k % 2) * nb:(k % 2 + 1) * nb]
+        for c in range(count):
+            buf[c] = torch.from_numpy(orc.chain_f32(xb[c], modes[start + c], hf, hf, sin4, cos4, state=state[c]))
+        buf2.copy_(buf)
+        og.submit(k)
+        og_all.submit(k)
+    og.finish(); og_all.finish()
+    ov_ok = torch.tensor([1.0])
+    last_all = og_all.result(blocks - 1)
+    if rank == 0:
+        got_blocks += [og.result(blocks - 2).clone(), og.result(blocks - 1).clone()]
+        st = [dict() for _ in range(total)]
+        for k in range(blocks):
+            want_k = np.stack([orc.chain_f32(x_all[c, (k % 2) * nb:(k % 2 + 1) * nb], modes[c], hf, hf, sin4, cos4, state=st[c]) for c in range(total)])
+            if not np.array_equal(got_blocks[k].numpy(), want_k):
+                ov_ok[0] = 0.0
+        if not torch.equal(last_all, got_blocks[-1]):
+            ov_ok[0] = 0.0
+    else:
+        assert og.result(blocks - 1) is None
+    dist.all_reduce(ov_ok, op=dist.ReduceOp.MIN)
     if rank == 0:
         want = np.stack([orc.chain_q15(x_all[c], modes[c], taps, taps) for c in range(total)])
-        q.put((bool(np.array_equal(full.numpy(), want)), slowest, (start, count)))
+        q.put((bool(np.array_equal(full.numpy(), want)) and bool(root_ok.item() == 1.0) and bool(ov_ok.item() == 1.0), slowest, (start, count)))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -23,7 +23,7 @@ agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
-        if ("chain_" in k and "kernel" in k) or "fir_f32mf" in k or "spectrum_rfft128" in k:
+        if ("chain_" in k and "kernel" in k) or "fir_f32" in k or "spectrum_rfft128" in k:
             a = agg[r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += 1
 for k in sorted(agg):

@@ -40,7 +40,7 @@ for name in ("fetch", "write"):
     for f in glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             kn = r.get("Kernel_Name", "")
-            if ("chain_" in kn and "kernel" in kn) or "spectrum_rfft128" in kn or "fir_f32mf" in kn:
+            if ("chain_" in kn and "kernel" in kn) or "spectrum_rfft128" in kn or "fir_f32" in kn:
                 tot += float(r.get("Counter_Value", 0)); cnt += 1
     res[name] = (tot, cnt)
     print("%s counter: %d chain_kernel dispatches, mean raw value %.1f" % (name.upper() + "_SIZE", cnt, tot / cnt if cnt else float("nan")))

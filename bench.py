@@ -1,16 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the fused demodulation chain on MI355X (one JSON line on rank 0).
+"""bench.py -- throughput of the demodulation path on MI355X (one JSON line on rank 0).
 
-A "step" is ONE pass of the hot path (IF -> I/Q mix -> FIR pair -> demod -> IIR cascade) over one
-block batch of synthetic IF that is already resident in HBM.  Workloads (BASELINE.json configs):
-  c2 (default)  1 SSB channel, freq_conv-style NCO tables, 100-tap Hilbert pair, LSB (I-Q), 2-stage biquad,
-                2^30 int16 IF samples per step, fp32 audio out                       [configs[1]]
-  c3            4096 AM channels x 2^18 samples, 256-tap fp32 low-pass pair, Fs/4 mixer  [configs[2]]
-  c4            8192 SSB channels per GPU x 2^14 samples, 100-tap pair, LSB              [configs[3]]
-  c5            mixed AM/LSB per channel, 512 taps, 1 Mi-sample blocks, 256 channels/GPU [configs[4]]
-Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  Channels are independent,
-so every rank runs its own shard with NO data-path collective ("weak" scaling); the RCCL gather of
-demodulated audio is timed separately, outside the timed region, and reported under "gather".
+A "step" is ONE pass of the hot path over one block batch of synthetic IF that is already resident in HBM.
+
+Default (no --workload): the HEADLINE is c3 = BASELINE.json configs[2], the north-star's "HBM-roofline run" (4096 AM channels,
+256-tap fp32 FIR pair, Fs/4 mix, envelope, 2-stage biquad; int16 in, fp32 out), timed as the contract says (W warm-up steps,
+exactly K steps between barriers, MAX over ranks).  The same line carries, under "also", the other single-GPU records of the
+path, each with its own timing, roofline and parity:
+  fir   the 256-tap fp32 FIR STAGE alone (arm_fir_f32, 8 B per sample) -- the stage the north-star's 70 % target names
+  c2    1 SSB channel, NCO tables at fs/4, 100-tap Hilbert pair, LSB, 2^30 int16 samples          [configs[1]]
+  c4    8192 SSB channels per GPU x 2^14 samples, 100-tap pair, LSB                               [configs[3]]
+  c5    256 mixed AM/LSB channels per GPU x 2^20 samples, 512 taps                                [configs[4]]
+--workload X runs one record alone (c2..c5, fir, plus fe = front end, spec = spectrum FFT).
+Parity is checked inside the run against the CPU oracle (test infrastructure, never the thing measured): the head of the
+stream from zero state AND windows that straddle the kernel's time-segment boundaries and the tail, each with an oracle
+pre-roll (as tests/test_gpu_fullsize.py does).
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  Channels are independent, so every rank runs its own
+shard with NO data-path collective ("weak" scaling); the RCCL gather of demodulated audio is timed separately, outside the
+timed region (all-gather, gather-to-root, and the double-buffered schedule that overlaps gather k with compute k + 1), and
+reported under "gather".  The CPU baseline runs on rank 0 whatever N is.
 """
 import argparse
 import json
@@ -208,13 +216,10 @@ def cpu_baseline_q15(wl, x_host, gpu_first, target_s=12.0):
                       % (xs.shape[0], per_row, passes, total_dt)}, bad, m
 
 
-def bench_frontend(args, torch, msdr, dev, rank, local_rank, world, dist):
+def bench_frontend(args, torch, msdr, ctx, dev, rank, world, dist):
     """Row f1: DC block + AudioAmplifier + AGC over 4096 channels x 2^18 raw conversions (integer, bit-exact).  One lane per
     channel (the recurrences are exact only in order), so this is latency-bound by construction; reported for completeness."""
     ch, n = args.channels or 4096, args.samples or (1 << 18)
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    ctx = msdr.Context(local_rank, stream.cuda_stream)
     g = torch.Generator(device=dev)
     g.manual_seed(11 + rank)
     t = torch.arange(n, device=dev, dtype=torch.float32)
@@ -244,7 +249,7 @@ def bench_frontend(args, torch, msdr, dev, rank, local_rank, world, dist):
         import msdr_dist
         dt = msdr_dist.max_over_ranks(dt, args.cdev)
     if rank != 0:
-        return
+        return None
     value = world * ch * n * args.steps / dt / 1e6
     ms = dt / args.steps * 1e3
     out = {"metric": "Msamples/s through the front end (DC block -> AudioAmplifier -> AGC); achieved HBM GB/s vs peak",
@@ -271,17 +276,14 @@ def bench_frontend(args, torch, msdr, dev, rank, local_rank, world, dist):
         out["cpu_baseline"] = {"value": round(xs.size / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
                                "sample": "%d channels x %d samples of the same input (oracle/msdr_oracle.c orc_frontend_run)" % xs.shape}
         out["parity"] = {"mismatching_samples": bad, "tolerance": 0}
-    print(json.dumps(out))
+    return out
 
 
-def bench_spectrum(args, torch, msdr, dev, rank, local_rank, world, dist):
+def bench_spectrum(args, torch, msdr, ctx, dev, rank, world, dist):
     """Row f4: the display's 128-point q15 real FFT + column heights (UI.cpp:520-592) over every 128-sample block of a
     4096-channel batch (the reference transforms one block in 25; here all of them, as a throughput figure)."""
     ch, n = args.channels or 4096, args.samples or (1 << 15)
     nfft = ch * (n // 128)
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    ctx = msdr.Context(local_rank, stream.cuda_stream)
     g = torch.Generator(device=dev)
     g.manual_seed(13 + rank)
     x = torch.randint(-20000, 20001, (nfft, 128), device=dev, generator=g, dtype=torch.int32).to(torch.int16)
@@ -311,7 +313,7 @@ def bench_spectrum(args, torch, msdr, dev, rank, local_rank, world, dist):
         import msdr_dist
         dt = msdr_dist.max_over_ranks(dt, args.cdev)
     if rank != 0:
-        return
+        return None
     ms = dt / args.steps * 1e3
     gbs = 896.0 * nfft / (ms * 1e-3) / 1e9
     out = {"metric": "Msamples/s through the spectrum FFT (arm_rfft_q15 128 points + column heights); achieved HBM GB/s vs peak",
@@ -337,17 +339,49 @@ def bench_spectrum(args, torch, msdr, dev, rank, local_rank, world, dist):
         out["cpu_baseline"] = {"value": round(k * 128 / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
                                "sample": "%d transforms of the same input through ctypes (oracle/msdr_oracle.c orc_rfft128_q15)" % k}
         out["parity"] = {"mismatching_values": bad, "tolerance": 0}
-    print(json.dumps(out))
+    return out
 
 
-def bench_fir_stage(args, torch, msdr, dev, rank, local_rank, world, dist):
+def host_info():
+    """nproc and CPU model of the box the CPU baseline runs on."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count() or 1, "cpu_model": model}
+
+
+def timed_steps(args, torch, dev, dist, step):
+    """The contract's timed region: W untimed warm-up steps, then exactly K steps between barrier + synchronize pairs;
+    returns the MAX over ranks of the wall time."""
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import msdr_dist
+        dt = msdr_dist.max_over_ranks(dt, args.cdev)
+    return dt
+
+
+def bench_fir_stage(args, torch, msdr, ctx, dev, rank, world, dist, do_cpu):
     """The FIR STAGE on its own (rows A4 / A6): arm_fir_f32 (fp32 in / fp32 out, 8 B per sample) or, with --arith q15,
     arm_fir_fast_q15 (int16 in / out, 4 B per sample), 256 taps, batched over 4096 channels x 2^18 samples."""
     ch, n, nt = args.channels or 4096, args.samples or (1 << 18), args.taps or 256
     q15 = args.arith == "q15"
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    ctx = msdr.Context(local_rank, stream.cuda_stream)
     g = torch.Generator(device=dev)
     g.manual_seed(17 + rank)
     lp = lowpass(nt)
@@ -363,61 +397,345 @@ def bench_fir_stage(args, torch, msdr, dev, rank, local_rank, world, dist):
         y = torch.empty((ch, n), dtype=torch.float32, device=dev)
         fir = msdr.FirF32(ctx, taps, ch)
         fn = ctx.lib.msdr_fir_f32_process
+    trn = "chain_q15mf_kernel<3> (i8 matrix cores)" if q15 else fir.kernel_name() + " (split-fp16 matrix cores)"
     import ctypes as C
 
     def step():
         if fn(fir.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_uint32(n)) != 0:
             raise SystemExit("fir process: %s" % ctx.lib.msdr_last_error().decode())
-    step()
+    step()                                                       # first pass from zero state: kept for the parity check
     torch.cuda.synchronize(dev)
-    first = y[:4, :1 << 14].cpu().numpy() if rank == 0 else None
-    for _ in range(max(0, args.warmup - 1)):
-        step()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import msdr_dist
-        dt = msdr_dist.max_over_ranks(dt, args.cdev)
+    # parity samples: head, the middle of the block (inside another time segment of the kernel), and the tail, on four channels
+    rows = sorted({0, 1, ch // 2, ch - 1})
+    L = min(n, 1 << 14)
+    los = sorted({0, max(0, n // 2 - L // 2), n - L})
+    pre = 2 * nt
+    keep = {(r, lo): (x[r, max(0, lo - pre):lo + L].cpu().numpy(), y[r, lo:lo + L].cpu().numpy()) for r in rows for lo in los} if rank == 0 else None
+    ctx.kernel_time()                                            # clear
+    ctx.enable_kernel_timing(True)
+    dt = timed_steps(args, torch, dev, dist, step)
+    k_total, launches = ctx.kernel_time()
+    ctx.enable_kernel_timing(False)
+    fir.close()
+    del x, y
+    torch.cuda.empty_cache()
     if rank != 0:
-        return
+        return None
     ms = dt / args.steps * 1e3
+    k_ms = k_total / max(1, launches)
     bps = 4.0 if q15 else 8.0
-    gbs = bps * ch * n / (ms * 1e-3) / 1e9
+    gbs = bps * ch * n / (k_ms * 1e-3) / 1e9
     out = {"metric": "Msamples/s through the %d-tap FIR stage alone (%s); achieved HBM GB/s vs peak" % (nt, "arm_fir_fast_q15" if q15 else "arm_fir_f32"),
            "value": round(world * ch * n * args.steps / dt / 1e6, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "q15" if q15 else "f32", "data": "synthetic",
-           "config": {"workload": "fir: %d channels x %d samples, %d taps, stage mirror msdr_fir_%s_process (includes its history kernel)" % (ch, n, nt, "q15" if q15 else "f32"),
-                      "kernel": "chain_q15mf_kernel<3> (i8 matrix cores)" if q15 else "fir_f32mf_kernel (split-fp16 matrix cores)"},
-           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                        "note": "%d B per sample; matrix-core stage kernels (DESIGN.md 4.4)" % int(bps)}}
-    if not args.no_cpu:
+           "dtype": "q15 (int16 data, wrapping int32 accumulate)" if q15 else "f32 (fp32 accumulate; operands as 2 x fp16 pieces = 22 bits, block floating point per tile)",
+           "data": "synthetic",
+           "config": {"workload": "fir: %d channels x %d samples, %d taps, stage mirror msdr_fir_%s_process" % (ch, n, nt, "q15" if q15 else "f32"),
+                      "kernel": trn},
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "traffic": None, "kernel_ms": round(k_ms, 4), "launches_timed": int(launches),
+                        "note": "%d B per sample; kernel_ms from HIP events around the stage's main kernel (its history kernel, ~6 us, is in ms_per_step only)" % int(bps)}}
+    attach_traffic(out, "fir_q15" if q15 else "fir_f32", args)
+    if do_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orclib
         orc = orclib.Oracle()
-        xs = x[:4, :1 << 14].cpu().numpy()
         t1 = time.perf_counter()
-        worst = 0.0
-        for c in range(xs.shape[0]):
+        worst, nsamp = 0.0, 0
+        for (r, lo), (xs, got) in keep.items():
+            skip = xs.size - got.size                            # pre-roll samples in front of the window
+            m = (xs.size // 128) * 128
             if q15:
-                rc, want = orc.fir_q15_blocks(taps, xs[c], 128)
-                worst = max(worst, float((want != first[c]).sum()))
+                _, want = orc.fir_q15_blocks(taps, xs[:m], 128)
+                want = want[skip:]
+                worst = max(worst, float((want != got[:want.size]).sum()))
             else:
-                want = orc.fir_f32_blocks(taps, xs[c], 128)
-                worst = max(worst, float(np.sqrt(((want.astype(np.float64) - first[c]) ** 2).sum() / max((want.astype(np.float64) ** 2).sum(), 1e-300))))
+                want = orc.fir_f32_blocks(taps, xs[:m], 128)[skip:].astype(np.float64)
+                worst = max(worst, float(np.sqrt(((want - got[:want.size]) ** 2).sum() / max((want ** 2).sum(), 1e-300))))
+            nsamp += xs.size
         cdt = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": round(xs.size / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-                               "sample": "%d channels x %d samples of the same input (oracle/msdr_oracle.c)" % xs.shape}
-        out["parity"] = {("mismatching_samples" if q15 else "rel_rms_worst"): float("%.3g" % worst), "tolerance": 0 if q15 else 1e-6}
-    print(json.dumps(out))
+        out["cpu_baseline"] = dict({"value": round(nsamp / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                                    "sample": "%d windows of the same input incl. pre-roll, through ctypes (oracle/msdr_oracle.c)" % len(keep)}, **host_info())
+        out["parity"] = {("mismatching_samples" if q15 else "rel_rms_worst"): float("%.3g" % worst), "tolerance": 0 if q15 else 1e-6,
+                         "windows": [{"channel": int(r), "start": int(lo), "length": int(L)} for (r, lo) in keep]}
+    return out
+
+
+def attach_traffic(out, tag, args):
+    """HBM traffic per launch of the dominant kernel.  The PMC passes cannot run inside this process (rocprofv3 wraps the command),
+    so the figure is the one tools/profile.sh measured for this workload at the commit stamped in the file and committed under
+    profiles/ (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, corrected as MI355X_MICROARCH.md prescribes); null when no such profile
+    is there or the shape was overridden."""
+    if args.samples or args.channels or args.taps or args.stages >= 0 or args.no_mfma:
+        return
+    for rnd in ("r02", "r01"):
+        prof = os.path.join(ROOT, "profiles", rnd, "%s_rocprof_summary.txt" % tag)
+        if not os.path.exists(prof):
+            continue
+        for line in open(prof):
+            if line.startswith("HBM traffic per chain_kernel launch") and "total" in line:
+                out["roofline"]["traffic"] = float(line.rsplit("total", 1)[1].split()[0])
+                out["roofline"]["traffic_source"] = "profiles/%s/%s_rocprof_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % (rnd, tag)
+        return
+
+
+def parity_windows(wl, info, x, y, q15, torch):
+    """(lo, length, channel) windows of the GPU output to check against the oracle: the head, stretches that straddle boundaries
+    between the kernel's time segments (first, middle, last boundary), and the tail; on the first, a middle and the last channel."""
+    ch, n = wl["channels"], wl["n"]
+    L = min(n, 4096)
+    nseg = max(1, int(info["time_segments"]))
+    tile = max(1, int(info["tile"]))
+    seg = -(-n // nseg)
+    seg = -(-seg // tile) * tile
+    los, bounds = [0], []
+    if nseg > 1 and seg < n:
+        last = (n - 1) // seg
+        for k in sorted({1, max(1, last // 2), last}):
+            if k * seg + L // 2 <= n and k * seg - L // 2 > 0:
+                los.append(k * seg - L // 2)
+                bounds.append(k * seg)
+    los.append(n - L)
+    chans = sorted({0, ch // 2, ch - 1})
+    wins = [(c, lo) for c in chans for lo in sorted(set(los))]
+    if q15 and len(wl["bq"]):            # the Teensy biquad nodes are nonlinear: their state cannot be re-created by a pre-roll
+        wins = [(c, 0) for c in chans]
+        bounds = []
+    return wins, L, bounds
+
+
+def chain_parity(wl, info, x, y, q15, torch, orc, orclib):
+    """GPU output against the oracle on parity_windows(); the oracle runs over [lo - preroll, lo + L) restarted on an oscillator
+    period boundary (FIR history and IIR state settle inside the pre-roll) -- tests/test_gpu_fullsize.py:_window_check."""
+    wins, L, bounds = parity_windows(wl, info, x, y, q15, torch)
+    osc_i, osc_q = wl["osc"] if wl["osc"] else (np.array([0, 1, 0, -1], np.float32), np.array([1, 0, -1, 0], np.float32))
+    period = 128 if wl["osc"] else 4
+    preroll = 8192
+    worst, checked = 0.0, 0
+    nodes = None
+    for c, lo in wins:
+        start = max(0, lo - preroll)
+        start -= start % period
+        xs = x[c, start:lo + L].cpu().numpy()
+        got = y[c, lo:lo + L].cpu().numpy()
+        mode = int(wl["modes"][c]) if wl["modes"] is not None else wl["mode"]
+        ts = int(wl["tapsets"][c]) if wl["tapsets"] is not None else 0
+        if q15:
+            m = (xs.size // 128) * 128
+            nodes = [orc.biquad_teensy_new(cf) for cf in wl["qnodes"]]
+            oi, oq = wl["qosc"] if wl["qosc"] else (None, None)
+            want = orc.chain_q15(xs[:m], mode, wl["qi"][ts], wl["qq"][ts], mixer=1 if oi is not None else 0, osc_i=oi, osc_q=oq,
+                                 biquads=nodes)[lo - start:]
+            worst = max(worst, float((want != got[:want.size]).sum()))
+        else:
+            want = orc.chain_f32(xs, mode, wl["ci"][ts], wl["cq"][ts], osc_i, osc_q, wl["bq"] if len(wl["bq"]) else None)[lo - start:].astype(np.float64)
+            worst = max(worst, float(np.sqrt(((want - got) ** 2).sum() / max((want ** 2).sum(), 1e-300))))
+        checked += L
+    return {("mismatching_samples" if q15 else "rel_rms_worst"): float("%.3g" % worst), "tolerance": 0 if q15 else 1e-5,
+            "windows": [{"channel": int(c), "start": int(lo), "length": int(L)} for c, lo in wins],
+            "segment_boundaries_covered": [int(b) for b in bounds], "oracle_preroll": preroll, "samples_checked": int(checked)}
+
+
+def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do_gather):
+    """One record of the fused chain (c2 .. c5)."""
+    wl = workload(name, msdr, rank, args.osc_period)
+    if args.samples:
+        wl["n"] = args.samples
+    if args.channels:
+        wl["channels"] = args.channels
+        if wl["modes"] is not None:
+            wl["modes"], wl["tapsets"] = np.resize(wl["modes"], args.channels), np.resize(wl["tapsets"], args.channels)
+    if args.stages >= 0:
+        wl["bq"] = wl["bq"][:args.stages]
+        wl["name"] += " [experiment: %d biquad stages]" % args.stages
+    if args.taps:
+        pair = len(wl["ci"]) == 1 and wl["mode"] == msdr.MODE_LSB
+        if pair:
+            hi, hq = hilbert_pair(args.taps)
+            wl["ci"], wl["cq"] = [hi], [hq]
+        else:
+            lp = lowpass(args.taps)
+            hi, hq = hilbert_pair(args.taps)
+            wl["ci"], wl["cq"] = ([lp], [lp]) if len(wl["ci"]) == 1 else ([lp, hi], [lp, hq])
+        wl["taps"] = args.taps
+        wl["name"] += " [experiment: %d taps]" % args.taps
+    ch, n = wl["channels"], wl["n"]
+    q15 = args.arith == "q15"
+    if q15:       # the same workload through the as-written integer chain: Q15 taps / oscillator, Teensy biquad nodes
+        corr = msdr.AUDIO_SAMPLE_RATE_EXACT / FS
+        wl["qi"] = [np.round(np.asarray(c, np.float64) * 32767).astype(np.int16) for c in wl["ci"]]
+        wl["qq"] = [np.round(np.asarray(c, np.float64) * 32767).astype(np.int16) for c in wl["cq"]]
+        wl["qosc"] = tuple(np.round(np.asarray(o, np.float64) * 32768).clip(-32768, 32767).astype(np.int16) for o in wl["osc"]) if wl["osc"] else None
+        wl["qnodes"] = [[msdr.biquad_design(msdr.BQ_LOWPASS, np.float32(6000 * 0.9 * corr), 0.54)],
+                        [msdr.biquad_design(msdr.BQ_NOTCH, np.float32(FS / 8 * corr), 15.0)]][:len(wl["bq"])]
+        chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, wl["qi"], wl["qq"], mixer=wl["mixer"], mode=wl["mode"], modes=wl["modes"],
+                           tapsets=wl["tapsets"], osc_i=wl["qosc"][0] if wl["qosc"] else None,
+                           osc_q=wl["qosc"][1] if wl["qosc"] else None, biquad_nodes=wl["qnodes"])
+    else:
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, wl["ci"], wl["cq"], mixer=wl["mixer"], mode=wl["mode"], modes=wl["modes"],
+                           tapsets=wl["tapsets"], osc_i=wl["osc"][0] if wl["osc"] else None, osc_q=wl["osc"][1] if wl["osc"] else None,
+                           biquad_coeffs=wl["bq"] if len(wl["bq"]) else None, time_segments=args.time_segments,
+                           flags=(msdr.CHAIN_NO_TAP_FOLDING if args.no_fold else 0) | (msdr.CHAIN_NO_FFT if args.no_fft else 0)
+                           | (msdr.CHAIN_NO_MFMA if args.no_mfma else 0))
+    x = synth_if(torch, dev, ch, n, wl["seed"])
+    y = torch.empty((ch, n), dtype=torch.int16 if q15 else torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
+
+    # first pass from zero state: kept for the parity checks (the timed passes continue the stream, state carried)
+    chain.process(x.data_ptr(), y.data_ptr(), n)
+    torch.cuda.synchronize(dev)
+    info = chain.info()
+    parity = None
+    first_rows = min(ch, os.cpu_count() or 1)
+    keep = min(n, 1 << 22)                                     # GPU audio kept for the head comparison with the timed CPU sample
+    keep_x = min(n, (1 << 26) if ch == 1 else (1 << 22))       # IF sample handed to the CPU baseline
+    gpu_first = None
+    if rank == 0 and (do_cpu or args.parity):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orclib
+        parity = chain_parity(wl, info, x, y, q15, torch, orclib.Oracle(), orclib)
+        if do_cpu:
+            gpu_first = y[:first_rows, :keep].cpu().numpy()
+    chain.enable_timing(True)
+    chain.kernel_time()
+    dt = timed_steps(args, torch, dev, dist, lambda: chain.process(x.data_ptr(), y.data_ptr(), n))
+    kernel_ms, launches = chain.kernel_time()
+    chain.enable_timing(False)
+
+    gather = None
+    if dist is not None and do_gather:                         # RCCL gather of demodulated audio, timed on its own
+        import msdr_dist
+        esz = y.element_size()
+        rows = max(1, min(ch, (1 << 24) // n)) if n <= (1 << 24) else 1
+        cols = min(n, 1 << 24)
+        part = y[:rows, :cols].contiguous().to(args.cdev)       # a bounded slice of this rank's audio shard
+        m = rows * cols
+
+        def timed(fn, reps=5):
+            fn()
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            g0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            return msdr_dist.max_over_ranks((time.perf_counter() - g0) / reps, args.cdev)
+        t_all = timed(lambda: msdr_dist.gather_audio(part, world * rows))
+        t_root = timed(lambda: msdr_dist.gather_audio_root(part, world * rows, root=0))
+        # double-buffered schedule on a 128-sample-per-channel cadence is launch-bound; use the bench block: compute into buffer
+        # k & 1, submit its gather, go on with block k + 1
+        og = msdr_dist.OverlappedGather(world * rows, rows, cols, y.dtype, args.cdev, root=0)
+        xs = x[:rows, :cols].contiguous()
+        blocks = 6
+
+        def pipeline(with_gather):
+            for k in range(blocks):
+                buf = og.buffer(k) if with_gather else og.bufs[k & 1]
+                if args.cdev.type == "cuda":
+                    chain_small.process(xs.data_ptr(), buf.data_ptr(), cols)
+                else:                                        # rehearsal: the audio buffers live on the host
+                    chain_small.process(xs.data_ptr(), ysmall.data_ptr(), cols)
+                    buf.copy_(ysmall)
+                if with_gather:
+                    og.submit(k)
+            if with_gather:
+                og.finish()
+        chain_small = make_chain(msdr, ctx, wl, rows, q15, args)
+        ysmall = torch.empty((rows, cols), dtype=y.dtype, device=dev)
+        t_comp = timed(lambda: pipeline(False), reps=2) / blocks
+        t_ovl = timed(lambda: pipeline(True), reps=2) / blocks
+        chain_small.close()
+        gather = {"audio_dtype": str(y.dtype).replace("torch.", ""), "bytes_per_rank": m * esz, "ranks": world,
+                  "rank_devices": args.rank_devices,
+                  "all_gather": {"op": "msdr_dist.gather_audio = all_gather_into_tensor", "ms": round(t_all * 1e3, 3),
+                                 "GBps_into_each_rank": round((world - 1) * m * esz / t_all / 1e9, 1), "Msamples_per_s": round(world * m / t_all / 1e6, 1)},
+                  "gather_to_root": {"op": "msdr_dist.gather_audio_root = gather(dst=0)", "ms": round(t_root * 1e3, 3),
+                                     "GBps_into_root": round((world - 1) * m * esz / t_root / 1e9, 1), "Msamples_per_s": round(world * m / t_root / 1e6, 1)},
+                  "overlapped": {"op": "msdr_dist.OverlappedGather: gather(k) to root while block k + 1 is demodulated, two audio buffers",
+                                 "block": "%d channels x %d samples per rank" % (rows, cols), "ms_per_block_compute_only": round(t_comp * 1e3, 3),
+                                 "ms_per_block_with_gather": round(t_ovl * 1e3, 3),
+                                 "gather_time_hidden_frac": round(max(0.0, min(1.0, 1.0 - (t_ovl - t_comp) / max(t_root, 1e-9))), 3)}}
+    x_host = x[:first_rows, :keep_x].cpu().numpy() if (rank == 0 and do_cpu) else None
+    chain.close()
+    del x, y
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+
+    samples_per_step = ch * n
+    value = world * samples_per_step * args.steps / dt / 1e6
+    k_ms = kernel_ms / max(launches, 1)
+    alg_bytes = (4.0 if q15 else 6.0) * samples_per_step        # int16 in + fp32 (or int16) out (SURVEY 8d)
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    extra = (6 if wl["mixer"] == msdr.MIXER_NCO else 0) + 4 + 9 * len(wl["bq"])
+    flop_written = 4.0 * wl["taps"] + extra                      # as the reference writes it: two N-tap FIRs (SURVEY 8d)
+    folded = info["kernel"].startswith("chain_fold")
+    flop_exec = (2.0 if folded else 4.0) * info["taps_padded"] + extra     # what the kernel executes (tap folding halves the MACs)
+    if info["kernel"].startswith("chain_fft"):                             # overlap-save: 2 complex 4096-point FFTs (5 F log2 F each) + pointwise
+        F = 4096.0                                                         # product (6 F) + mixer (2 F) per block of `tile` outputs
+        flop_exec = (2 * 5 * F * 12 + 8 * F) / info["tile"] + 4 + 9 * len(wl["bq"])
+    out = {
+        "metric": "Msamples/s through IF->I/Q->FIR->demod->IIR chain; achieved HBM GB/s vs peak",
+        "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "q15 (int16 data, wrapping int32 accumulate)" if q15 else "f32 (fp32 accumulate; matrix-core operands as 2 x fp16 pieces: int16 samples exact, taps 22 bits)",
+        "data": "synthetic",
+        "config": {"workload": wl["name"], "channels_per_gpu": ch, "samples_per_channel_per_step": n, "taps": wl["taps"],
+                   "biquad_stages": int(len(wl["bq"])), "in": "int16", "out": "int16" if q15 else "fp32", "sharding": "independent channels per GPU, no data-path collective",
+                   "kernel": info["kernel"], "grid": info["grid"], "time_segments": info["time_segments"], "iir_warmup": info["warmup"],
+                   "tap_folding": not args.no_fold},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel_ms": round(k_ms, 4), "launches_timed": int(launches),
+                     "valu_tflops_executed": round(flop_exec * samples_per_step / (k_ms * 1e-3) / 1e12, 2),
+                     "valu_frac_executed": round(flop_exec * samples_per_step / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4),
+                     "valu_peak_tflops": VALU_PEAK_TFLOPS,
+                     "as_written_equivalent_tflops": round(flop_written * samples_per_step / (k_ms * 1e-3) / 1e12, 2)},
+    }
+    if info["kernel"].startswith("chain_mf") or info["kernel"].startswith("chain_tr"):
+        # matrix-core kernel: the folded FIR runs as 3 fp16 matrix products (32768 flop each in 32x32x16 terms) per k-step and
+        # 1024-output wave tile; the vector ALU only carries staging, demod and the IIR scan, so the valu_* fields do not apply
+        r = out["roofline"]
+        for k in ("valu_tflops_executed", "valu_frac_executed", "valu_peak_tflops"):
+            r.pop(k)
+        mf = 3 * 32768.0 * info["mfma_ksteps"] / 1024.0
+        r["mfma_f16_tflops_executed"] = round(mf * samples_per_step / (k_ms * 1e-3) / 1e12, 1)
+        r["mfma_f16_frac"] = round(mf * samples_per_step / (k_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
+        r["mfma_f16_peak_tflops"] = MFMA_F16_PEAK_TFLOPS
+    if info["kernel"].startswith("chain_q15mf"):
+        # integer matrix-core kernel: four v_mfma_i32_32x32x32_i8 (65536 integer ops each) per k-step and 1024-output wave tile
+        r = out["roofline"]
+        for k in ("valu_tflops_executed", "valu_frac_executed", "valu_peak_tflops"):
+            r.pop(k, None)
+        mi = 4 * 65536.0 * info["mfma_ksteps"] / 1024.0
+        r["mfma_i8_tops_executed"] = round(mi * samples_per_step / (k_ms * 1e-3) / 1e12, 1)
+        r["mfma_i8_frac"] = round(mi * samples_per_step / (k_ms * 1e-3) / 1e12 / (2 * MFMA_F16_PEAK_TFLOPS), 4)
+        r["mfma_i8_peak_tops"] = 2 * MFMA_F16_PEAK_TFLOPS
+        r["note"] = "kernel_ms / achieved are the FIR + demod kernel (4 B/sample); the step also runs the Teensy biquad nodes (serial per channel)"
+    attach_traffic(out, ("q15_" if q15 else "") + name, args)
+    if gather:
+        out["gather"] = gather
+    if do_cpu:
+        cb, worst, per_row = cpu_baseline_q15(wl, x_host, gpu_first) if q15 else cpu_baseline(wl, x_host, gpu_first)
+        out["cpu_baseline"] = dict(cb, **host_info())
+        parity["head_vs_timed_cpu_sample"] = {("mismatching_samples" if q15 else "rel_rms_worst"): float("%.3g" % worst),
+                                              "rows": int(min(first_rows, max(1, x_host.shape[0]))), "samples_per_row": int(per_row)}
+    if parity is not None:
+        out["parity"] = parity
+    return out
+
+
+def make_chain(msdr, ctx, wl, channels, q15, args):
+    """The workload's chain for `channels` channels (the gather pipeline runs it on a bounded slice of the shard)."""
+    modes = wl["modes"][:channels] if wl["modes"] is not None else None
+    tapsets = wl["tapsets"][:channels] if wl["tapsets"] is not None else None
+    if q15:
+        return msdr.Chain(ctx, msdr.ARITH_Q15, channels, wl["qi"], wl["qq"], mixer=wl["mixer"], mode=wl["mode"], modes=modes, tapsets=tapsets,
+                          osc_i=wl["qosc"][0] if wl["qosc"] else None, osc_q=wl["qosc"][1] if wl["qosc"] else None, biquad_nodes=wl["qnodes"])
+    return msdr.Chain(ctx, msdr.ARITH_F32, channels, wl["ci"], wl["cq"], mixer=wl["mixer"], mode=wl["mode"], modes=modes, tapsets=tapsets,
+                      osc_i=wl["osc"][0] if wl["osc"] else None, osc_q=wl["osc"][1] if wl["osc"] else None,
+                      biquad_coeffs=wl["bq"] if len(wl["bq"]) else None)
 
 
 def main():
@@ -425,11 +743,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "fe", "spec", "fir"],
-                    help="c2..c5 = BASELINE.json configs[1..4]; fe = the front end (SURVEY 8 f1) on the c3 shape; spec = the spectrum FFT (f4)")
+    ap.add_argument("--workload", default="all", choices=["all", "c2", "c3", "c4", "c5", "fe", "spec", "fir"],
+                    help="all (default) = headline c3 (BASELINE.json configs[2]) with fir / c2 / c4 / c5 as sub-records; c2..c5 = configs[1..4] alone; "
+                         "fir = the FIR stage alone; fe = the front end (SURVEY 8 f1); spec = the spectrum FFT (f4)")
     ap.add_argument("--samples", type=int, default=0, help="override samples per channel per step")
     ap.add_argument("--channels", type=int, default=0, help="override channels per GPU")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (the windowed parity check stays unless --no-parity)")
+    ap.add_argument("--no-parity", dest="parity", action="store_false", help="skip the in-run parity check too")
     ap.add_argument("--no-fold", action="store_true", help="keep mixer and FIR as separate arithmetic steps")
     ap.add_argument("--no-fft", action="store_true", help="never use the overlap-save FFT kernel")
     ap.add_argument("--no-mfma", action="store_true", help="keep the folded FIR on the fp32 VALU (no split-fp16 matrix-core kernel)")
@@ -459,6 +779,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    args.rank_devices = ["cuda:%d" % local_rank]
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -466,187 +787,49 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        names = [None] * world
+        dist.all_gather_object(names, "rank %d: cuda:%d (%s)" % (rank, local_rank, torch.cuda.get_device_name(dev)))
+        args.rank_devices = names
+        assert dist.get_world_size() == world
     args.cdev = torch.device("cpu") if rehearsal else dev      # where the collectives' tensors live
-
-    if args.workload == "fe":
-        return bench_frontend(args, torch, msdr, dev, rank, local_rank, world, dist)
-    if args.workload == "spec":
-        return bench_spectrum(args, torch, msdr, dev, rank, local_rank, world, dist)
-    if args.workload == "fir":
-        return bench_fir_stage(args, torch, msdr, dev, rank, local_rank, world, dist)
-    wl = workload(args.workload, msdr, rank, args.osc_period)
-    if args.samples:
-        wl["n"] = args.samples
-    if args.channels:
-        wl["channels"] = args.channels
-        if wl["modes"] is not None:
-            wl["modes"], wl["tapsets"] = np.resize(wl["modes"], args.channels), np.resize(wl["tapsets"], args.channels)
-    if args.stages >= 0:
-        wl["bq"] = wl["bq"][:args.stages]
-        wl["name"] += " [experiment: %d biquad stages]" % args.stages
-    if args.taps:
-        pair = len(wl["ci"]) == 1 and wl["mode"] == msdr.MODE_LSB
-        if pair:
-            hi, hq = hilbert_pair(args.taps)
-            wl["ci"], wl["cq"] = [hi], [hq]
-        else:
-            lp = lowpass(args.taps)
-            hi, hq = hilbert_pair(args.taps)
-            wl["ci"], wl["cq"] = ([lp], [lp]) if len(wl["ci"]) == 1 else ([lp, hi], [lp, hq])
-        wl["taps"] = args.taps
-        wl["name"] += " [experiment: %d taps]" % args.taps
-    ch, n = wl["channels"], wl["n"]
 
     # One explicit HIP stream shared by torch (input synthesis, events, RCCL ordering) and the library.
     # (torch's default stream is the NULL stream, which msdr_ctx_create reads as "create your own".)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx = msdr.Context(local_rank, stream.cuda_stream)
-    q15 = args.arith == "q15"
-    if q15:       # the same workload through the as-written integer chain: Q15 taps / oscillator, Teensy biquad nodes
-        corr = msdr.AUDIO_SAMPLE_RATE_EXACT / FS
-        wl["qi"] = [np.round(np.asarray(c, np.float64) * 32767).astype(np.int16) for c in wl["ci"]]
-        wl["qq"] = [np.round(np.asarray(c, np.float64) * 32767).astype(np.int16) for c in wl["cq"]]
-        wl["qosc"] = tuple(np.round(np.asarray(o, np.float64) * 32768).clip(-32768, 32767).astype(np.int16) for o in wl["osc"]) if wl["osc"] else None
-        wl["qnodes"] = [[msdr.biquad_design(msdr.BQ_LOWPASS, np.float32(6000 * 0.9 * corr), 0.54)],
-                        [msdr.biquad_design(msdr.BQ_NOTCH, np.float32(FS / 8 * corr), 15.0)]][:len(wl["bq"])]
-        chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, wl["qi"], wl["qq"], mixer=wl["mixer"], mode=wl["mode"], modes=wl["modes"],
-                           tapsets=wl["tapsets"], osc_i=wl["qosc"][0] if wl["qosc"] else None,
-                           osc_q=wl["qosc"][1] if wl["qosc"] else None, biquad_nodes=wl["qnodes"])
+    do_cpu = not args.no_cpu
+
+    if args.workload == "fe":
+        out = bench_frontend(args, torch, msdr, ctx, dev, rank, world, dist)
+    elif args.workload == "spec":
+        out = bench_spectrum(args, torch, msdr, ctx, dev, rank, world, dist)
+    elif args.workload == "fir":
+        out = bench_fir_stage(args, torch, msdr, ctx, dev, rank, world, dist, do_cpu)
+    elif args.workload != "all":
+        out = bench_chain(args, args.workload, torch, msdr, ctx, dev, rank, world, dist, do_cpu, True)
     else:
-        chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, wl["ci"], wl["cq"], mixer=wl["mixer"], mode=wl["mode"], modes=wl["modes"],
-                           tapsets=wl["tapsets"], osc_i=wl["osc"][0] if wl["osc"] else None, osc_q=wl["osc"][1] if wl["osc"] else None,
-                           biquad_coeffs=wl["bq"] if len(wl["bq"]) else None, time_segments=args.time_segments,
-                           flags=(msdr.CHAIN_NO_TAP_FOLDING if args.no_fold else 0) | (msdr.CHAIN_NO_FFT if args.no_fft else 0)
-                           | (msdr.CHAIN_NO_MFMA if args.no_mfma else 0))
-    x = synth_if(torch, dev, ch, n, wl["seed"])
-    y = torch.empty((ch, n), dtype=torch.int16 if q15 else torch.float32, device=dev)
-    torch.cuda.synchronize(dev)
-
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    # first pass from zero state: kept for the parity check against the oracle
-    chain.process(x.data_ptr(), y.data_ptr(), n)
-    torch.cuda.synchronize(dev)
-    first_rows = min(ch, os.cpu_count() or 1)
-    keep = min(n, 1 << 22)                                     # GPU audio kept for the parity check
-    keep_x = min(n, (1 << 26) if ch == 1 else (1 << 22))       # IF sample handed to the CPU baseline
-    gpu_first = y[:first_rows, :keep].cpu().numpy() if rank == 0 else None
-    for _ in range(max(0, args.warmup - 1)):
-        chain.process(x.data_ptr(), y.data_ptr(), n)
-    chain.enable_timing(True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        chain.process(x.data_ptr(), y.data_ptr(), n)
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms, launches = chain.kernel_time()
-    chain.enable_timing(False)
+        out = bench_chain(args, "c3", torch, msdr, ctx, dev, rank, world, dist, do_cpu, True)      # the headline, with the CPU baseline
+        also = {}
+        if args.arith == "f32":
+            also["fir"] = bench_fir_stage(args, torch, msdr, ctx, dev, rank, world, dist, do_cpu)
+        for name in ("c2", "c4", "c5"):
+            also[name] = bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, False, False)   # parity windows, no timed CPU leg
+        if rank == 0:
+            for k, rec in also.items():
+                for drop in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "data"):
+                    rec.pop(drop, None)
+            out["also"] = also
+            out["config"]["records"] = "headline = c3 (BASELINE.json configs[2]); also: fir (256-tap fp32 FIR stage alone), c2, c4, c5 -- each timed with the same K and W"
+    if rank == 0:
+        out["n_ranks_seen"] = dist.get_world_size() if dist is not None else 1
+        out["rank_devices"] = args.rank_devices
+        if rehearsal:
+            out["rehearsal"] = "all %d ranks shared ONE GPU, gloo collectives on host tensors: control-flow dry run, not a measurement" % world
+        print(json.dumps(out))
+    ctx.close()
     if dist is not None:
-        import msdr_dist
-        dt = msdr_dist.max_over_ranks(dt, args.cdev)
-
-    gather = None
-    if dist is not None:                                       # RCCL gather of demodulated audio, timed on its own
-        rows = max(1, min(ch, (1 << 24) // n)) if n <= (1 << 24) else 1
-        cols = min(n, 1 << 24)
-        part = y[:rows, :cols].contiguous().to(args.cdev)       # a bounded slice of this rank's audio shard
-        full = msdr_dist.gather_audio(part, world * rows)
-        barrier()
-        g0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            full = msdr_dist.gather_audio(part, world * rows)
-        barrier()
-        gdt = (time.perf_counter() - g0) / reps
-        m = rows * cols
-        gather = {"op": "msdr_dist.gather_audio = all_gather_into_tensor over RCCL", "bytes_per_rank": m * 4, "ms": round(gdt * 1e3, 3),
-                  "GBps_into_each_rank": round((world - 1) * m * 4 / gdt / 1e9, 1),
-                  "Msamples_per_s": round(world * m / gdt / 1e6, 1)}
-
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-
-    info = chain.info()
-    samples_per_step = ch * n
-    value = world * samples_per_step * args.steps / dt / 1e6
-    k_ms = kernel_ms / max(launches, 1)
-    alg_bytes = (4.0 if q15 else 6.0) * samples_per_step        # int16 in + fp32 (or int16) out
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    extra = (6 if wl["mixer"] == msdr.MIXER_NCO else 0) + 4 + 9 * len(wl["bq"])
-    flop_written = 4.0 * wl["taps"] + extra                      # as the reference writes it: two N-tap FIRs
-    folded = info["kernel"].startswith("chain_fold")
-    flop_exec = (2.0 if folded else 4.0) * info["taps_padded"] + extra     # what the kernel executes (tap folding halves the MACs)
-    if info["kernel"].startswith("chain_fft"):                             # overlap-save: 2 complex 4096-point FFTs (5 F log2 F each) + pointwise
-        F = 4096.0                                                         # product (6 F) + mixer (2 F) per block of `tile` outputs
-        flop_exec = (2 * 5 * F * 12 + 8 * F) / info["tile"] + 4 + 9 * len(wl["bq"])
-    out = {
-        "metric": "Msamples/s through IF->I/Q->FIR->demod->IIR chain; achieved HBM GB/s vs peak",
-        "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "q15 (int16 data, int32 accumulate)" if q15 else "f32", "data": "synthetic",
-        "config": {"workload": wl["name"], "channels_per_gpu": ch, "samples_per_channel_per_step": n, "taps": wl["taps"],
-                   "biquad_stages": int(len(wl["bq"])), "in": "int16", "out": "int16" if q15 else "fp32", "sharding": "independent channels per GPU, no data-path collective",
-                   "kernel": info["kernel"], "grid": info["grid"], "time_segments": info["time_segments"], "iir_warmup": info["warmup"],
-                   "tap_folding": not args.no_fold},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel_ms": round(k_ms, 4), "launches_timed": int(launches),
-                     "valu_tflops_executed": round(flop_exec * samples_per_step / (k_ms * 1e-3) / 1e12, 2),
-                     "valu_frac_executed": round(flop_exec * samples_per_step / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4),
-                     "valu_peak_tflops": VALU_PEAK_TFLOPS,
-                     "as_written_equivalent_tflops": round(flop_written * samples_per_step / (k_ms * 1e-3) / 1e12, 2)},
-    }
-    if info["kernel"].startswith("chain_mf"):
-        # matrix-core kernel: the folded FIR runs as 3 v_mfma_f32_32x32x16_f16 (32768 flop each) per k-step and 1024-output
-        # wave tile; the vector ALU only carries staging, demod and the IIR scan, so the valu_* fields do not apply
-        r = out["roofline"]
-        for k in ("valu_tflops_executed", "valu_frac_executed", "valu_peak_tflops"):
-            r.pop(k)
-        mf = 3 * 32768.0 * info["mfma_ksteps"] / 1024.0
-        r["mfma_f16_tflops_executed"] = round(mf * samples_per_step / (k_ms * 1e-3) / 1e12, 1)
-        r["mfma_f16_frac"] = round(mf * samples_per_step / (k_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
-        r["mfma_f16_peak_tflops"] = MFMA_F16_PEAK_TFLOPS
-    if info["kernel"].startswith("chain_q15mf"):
-        # integer matrix-core kernel: four v_mfma_i32_32x32x32_i8 (65536 integer ops each) per k-step and 1024-output wave tile
-        r = out["roofline"]
-        for k in ("valu_tflops_executed", "valu_frac_executed", "valu_peak_tflops"):
-            r.pop(k)
-        mi = 4 * 65536.0 * info["mfma_ksteps"] / 1024.0
-        r["mfma_i8_tops_executed"] = round(mi * samples_per_step / (k_ms * 1e-3) / 1e12, 1)
-        r["mfma_i8_frac"] = round(mi * samples_per_step / (k_ms * 1e-3) / 1e12 / (2 * MFMA_F16_PEAK_TFLOPS), 4)
-        r["mfma_i8_peak_tops"] = 2 * MFMA_F16_PEAK_TFLOPS
-        r["note"] = "kernel_ms / achieved are the FIR + demod kernel (4 B/sample); the step also runs the Teensy biquad nodes (serial per channel)"
-    # HBM traffic per launch of the dominant kernel: the PMC passes cannot run inside this process (rocprofv3 wraps the command), so
-    # the figure is the one tools/profile.sh measured for this workload and committed under profiles/ (FETCH_SIZE x 1024 x 2 +
-    # WRITE_SIZE x 1024, corrected as MI355X_MICROARCH.md prescribes); null when no such profile is there or the shape was overridden
-    prof = os.path.join(ROOT, "profiles", "r01", "%s_rocprof_summary.txt" % args.workload)
-    if os.path.exists(prof) and not (args.samples or args.channels or args.taps or args.stages >= 0 or q15 or args.no_mfma):
-        for line in open(prof):
-            if line.startswith("HBM traffic per chain_kernel launch") and "total" in line:
-                out["roofline"]["traffic"] = float(line.rsplit("total", 1)[1].split()[0])
-                out["roofline"]["traffic_source"] = "profiles/r01/%s_rocprof_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % args.workload
-    if gather:
-        out["gather"] = gather
-    if os.environ.get("MSDR_BENCH_REHEARSAL", "0") == "1" and world > 1:
-        out["rehearsal"] = "all %d ranks shared ONE GPU, gloo collectives on host tensors: control-flow dry run, not a measurement" % world
-    if not args.no_cpu and world == 1:
-        x_host = x[:first_rows, :keep_x].cpu().numpy()
-        cb, worst, per_row = cpu_baseline_q15(wl, x_host, gpu_first) if q15 else cpu_baseline(wl, x_host, gpu_first)
-        out["cpu_baseline"] = cb
-        out["parity"] = {("mismatching_samples" if q15 else "rel_rms_worst"): float("%.3g" % worst), "tolerance": 0 if q15 else 1e-5, "rows": int(min(first_rows, max(1, x_host.shape[0]))),
-                         "samples_per_row": int(per_row)}
-    elif not args.no_cpu:
-        out["cpu_baseline"] = None
-    print(json.dumps(out))
-    if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

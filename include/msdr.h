@@ -139,6 +139,7 @@ typedef struct msdr_fir_f32 msdr_fir_f32;
 int msdr_fir_f32_create(msdr_ctx *ctx, uint16_t numTaps, const float32_t *pCoeffs, uint32_t channels, msdr_fir_f32 **out);
 int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, float32_t *d_dst, uint32_t blockSize);
 int msdr_fir_f32_reset(msdr_fir_f32 *S);
+const char *msdr_fir_f32_kernel_name(msdr_fir_f32 *S);      /* the kernel msdr_fir_f32_process launches for this instance */
 /* Filters of 16..513 taps run on the matrix cores with the samples as two fp16 pieces (22 bits) after a power-of-two scale.  By
  * default the scale is chosen per 1024-sample tile from the data (block floating point): nothing to declare.  max_abs > 0 pins
  * one scale for samples below that magnitude (saves the per-tile maximum; samples above it would overflow); 0 = automatic again.

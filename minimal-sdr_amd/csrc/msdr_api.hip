@@ -807,6 +807,15 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
     return 0;
 }
 extern "C" int msdr_fir_f32_reset(msdr_fir_f32 *S) { return fir_reset(S); }
+// which kernel msdr_fir_f32_process launches for this instance (benchmarks / tests)
+extern "C" const char *msdr_fir_f32_kernel_name(msdr_fir_f32 *S)
+{
+    static thread_local char name[64];
+    if (!S) return "";
+    if (S->d_tr_tab) snprintf(name, sizeof name, "fir_f32tr_kernel<%d, %s>", S->tr_ns, S->tr_skip1 ? "true" : "false");
+    else snprintf(name, sizeof name, "%s", S->d_fm_tab ? "fir_f32mf_kernel" : "fir_kernel<FirF32>");
+    return name;
+}
 extern "C" int msdr_fir_f32_destroy(msdr_fir_f32 *S)
 {
     if (S) { hipFree(S->d_fm_tab); hipFree(S->d_tr_tab); }

@@ -318,6 +318,12 @@ class FirF32(_Instance):
     def set_input_range(self, max_abs):
         _ck(self.ctx.lib.msdr_fir_f32_set_input_range(self.h, C.c_float(max_abs)))
 
+    def kernel_name(self):
+        f = self.ctx.lib.msdr_fir_f32_kernel_name
+        f.restype = C.c_char_p
+        f.argtypes = [_p]
+        return f(self.h).decode()
+
 
 class BiquadDf1F32(_Instance):
     """arm_biquad_cascade_df1_init_f32 / arm_biquad_cascade_df1_f32, batched over channels."""

@@ -1,0 +1,96 @@
+// msdr_cmsis.cpp -- include/msdr_cmsis.h: the reference's CMSIS-DSP argument lists over the batched C ABI (no device code here).
+#include "../../include/msdr_cmsis.h"
+
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+
+namespace {
+
+struct Entry { int kind; void *handle; };          // kind: 0 fir q15, 1 fir f32, 2 biquad df1 f32
+struct Binding {
+    std::mutex mu;
+    msdr_ctx *ctx = nullptr;
+    uint32_t channels = 0;
+    std::unordered_map<const void *, Entry> inst;  // keyed by the caller's instance struct, as CMSIS identifies a filter
+};
+Binding &binding() { static Binding b; return b; }
+
+void destroy(const Entry &e)
+{
+    if (e.kind == 0) msdr_fir_q15_destroy((msdr_fir_q15 *)e.handle);
+    else if (e.kind == 1) msdr_fir_f32_destroy((msdr_fir_f32 *)e.handle);
+    else msdr_biquad_df1_f32_destroy((msdr_biquad_df1_f32 *)e.handle);
+}
+// registers (or replaces: a re-init of the same instance) the device object behind S
+void remember(const void *S, int kind, void *handle)
+{
+    Binding &b = binding();
+    auto it = b.inst.find(S);
+    if (it != b.inst.end()) { destroy(it->second); it->second = Entry{kind, handle}; }
+    else b.inst.emplace(S, Entry{kind, handle});
+}
+void *lookup(const void *S, int kind)
+{
+    Binding &b = binding();
+    std::lock_guard<std::mutex> g(b.mu);
+    auto it = b.inst.find(S);
+    return (it != b.inst.end() && it->second.kind == kind) ? it->second.handle : nullptr;
+}
+
+}  // namespace
+
+extern "C" int msdr_cmsis_bind(msdr_ctx *ctx, uint32_t channels)
+{
+    Binding &b = binding();
+    std::lock_guard<std::mutex> g(b.mu);
+    for (auto &kv : b.inst) destroy(kv.second);    // objects of the previous binding go with it
+    b.inst.clear();
+    b.ctx = ctx; b.channels = ctx ? channels : 0;
+    return (ctx && channels == 0) ? MSDR_STATUS_ARGUMENT_ERROR : MSDR_STATUS_SUCCESS;
+}
+
+extern "C" msdr_arm_status msdr_arm_fir_init_q15(msdr_arm_fir_instance_q15 *S, uint16_t numTaps, q15_t *pCoeffs, q15_t *pState, uint32_t blockSize)
+{
+    if (numTaps & 1u) return MSDR_ARM_MATH_ARGUMENT_ERROR;                       // arm_fir_init_q15.c:93-96: status only, S untouched
+    S->numTaps = numTaps; S->pCoeffs = pCoeffs; S->pState = pState;              // :100-109
+    if (pState) memset(pState, 0, ((size_t)numTaps + blockSize) * sizeof(q15_t));   // :106
+    Binding &b = binding();
+    std::lock_guard<std::mutex> g(b.mu);
+    msdr_fir_q15 *h = nullptr;
+    if (!b.ctx || msdr_fir_q15_create(b.ctx, numTaps, pCoeffs, b.channels, &h) != 0) return MSDR_ARM_MATH_ARGUMENT_ERROR;
+    remember(S, 0, h);
+    return MSDR_ARM_MATH_SUCCESS;
+}
+extern "C" void msdr_arm_fir_fast_q15(const msdr_arm_fir_instance_q15 *S, q15_t *pSrc, q15_t *pDst, uint32_t blockSize)
+{
+    if (void *h = lookup(S, 0)) (void)msdr_fir_q15_process((msdr_fir_q15 *)h, pSrc, pDst, blockSize);
+}
+
+extern "C" void msdr_arm_fir_init_f32(msdr_arm_fir_instance_f32 *S, uint16_t numTaps, float32_t *pCoeffs, float32_t *pState, uint32_t blockSize)
+{
+    S->numTaps = numTaps; S->pCoeffs = pCoeffs; S->pState = pState;
+    if (pState && numTaps) memset(pState, 0, ((size_t)numTaps + blockSize - 1u) * sizeof(float32_t));     // state length arm_math.h:1050
+    Binding &b = binding();
+    std::lock_guard<std::mutex> g(b.mu);
+    msdr_fir_f32 *h = nullptr;
+    if (b.ctx && msdr_fir_f32_create(b.ctx, numTaps, pCoeffs, b.channels, &h) == 0) remember(S, 1, h);
+}
+extern "C" void msdr_arm_fir_f32(const msdr_arm_fir_instance_f32 *S, float32_t *pSrc, float32_t *pDst, uint32_t blockSize)
+{
+    if (void *h = lookup(S, 1)) (void)msdr_fir_f32_process((msdr_fir_f32 *)h, pSrc, pDst, blockSize);
+}
+
+extern "C" void msdr_arm_biquad_cascade_df1_init_f32(msdr_arm_biquad_casd_df1_inst_f32 *S, uint8_t numStages, float32_t *pCoeffs, float32_t *pState)
+{
+    S->numStages = numStages; S->pCoeffs = pCoeffs; S->pState = pState;
+    if (pState) memset(pState, 0, (size_t)4 * numStages * sizeof(float32_t));    // 4 state values per stage, arm_math.h:1233
+    Binding &b = binding();
+    std::lock_guard<std::mutex> g(b.mu);
+    msdr_biquad_df1_f32 *h = nullptr;
+    if (b.ctx && msdr_biquad_df1_f32_create(b.ctx, numStages, pCoeffs, b.channels, &h) == 0) remember(S, 2, h);
+}
+extern "C" void msdr_arm_biquad_cascade_df1_f32(const msdr_arm_biquad_casd_df1_inst_f32 *S, float32_t *pSrc, float32_t *pDst, uint32_t blockSize)
+{
+    if (void *h = lookup(S, 2)) (void)msdr_biquad_df1_f32_process((msdr_biquad_df1_f32 *)h, pSrc, pDst, blockSize);
+}

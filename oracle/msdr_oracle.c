@@ -11,6 +11,13 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+/* The batch drivers double as the timed CPU baseline: the two fp32 FIR loops are compiled once per vector ISA and picked at load
+ * time (the library is built in one container and run on another host, so -march=native is out). */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define ORC_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+#else
+#define ORC_CLONES
+#endif
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -202,13 +209,26 @@ void orc_fir_init_f32(orc_fir_instance_f32 *S, uint16_t numTaps, const float *pC
     S->numTaps = numTaps; S->pCoeffs = pCoeffs; S->pState = pState;
     memset(pState, 0, ((size_t)numTaps + blockSize - 1u) * sizeof(float));
 }
-void orc_fir_f32(const orc_fir_instance_f32 *S, const float *pSrc, float *pDst,
+#define ORC_FB 16u
+ORC_CLONES void orc_fir_f32(const orc_fir_instance_f32 *S, const float *pSrc, float *pDst,
                  uint32_t blockSize)
 {
     const uint32_t N = S->numTaps;
     float *w = S->pState;
     memcpy(w + (N - 1), pSrc, blockSize * sizeof(float));
-    for (uint32_t n = 0; n < blockSize; n++) {
+    uint32_t n = 0;
+    /* ORC_FB outputs side by side: each output's sum is still built from 0 in ascending k, one separately rounded multiply and
+     * one add per tap (the compiler may put the ORC_FB independent chains into vector lanes; it may not reorder any of them) */
+    for (; n + ORC_FB <= blockSize; n += ORC_FB) {
+        float acc[ORC_FB];
+        for (uint32_t j = 0; j < ORC_FB; j++) acc[j] = 0.0f;
+        for (uint32_t k = 0; k < N; k++) {
+            const float c = S->pCoeffs[k];
+            for (uint32_t j = 0; j < ORC_FB; j++) acc[j] += w[n + j + k] * c;
+        }
+        for (uint32_t j = 0; j < ORC_FB; j++) pDst[n + j] = acc[j];
+    }
+    for (; n < blockSize; n++) {
         float acc = 0.0f;
         for (uint32_t k = 0; k < N; k++) acc += w[n + k] * S->pCoeffs[k];
         pDst[n] = acc;
@@ -491,7 +511,7 @@ void orc_chain_q15(const orc_chain_q15_cfg *cfg, orc_chain_q15_state *st, const 
  * arm_fir_f32 pair (A6) -> demod (A5 in fp32) -> arm_biquad_cascade_df1_f32 (A8).
  * Sample-sequential; every product and sum is a separately rounded fp32 operation.
  * ====================================================================================== */
-void orc_chain_f32(const orc_chain_f32_cfg *cfg, orc_chain_f32_state *st, const int16_t *x,
+ORC_CLONES void orc_chain_f32(const orc_chain_f32_cfg *cfg, orc_chain_f32_state *st, const int16_t *x,
                    float *audio, uint64_t n)
 {
     const uint32_t N = cfg->num_taps, H = N - 1;
@@ -499,6 +519,8 @@ void orc_chain_f32(const orc_chain_f32_cfg *cfg, orc_chain_f32_state *st, const 
     const uint32_t CH = 4096;
     float *wi = (float *)malloc((size_t)(H + CH) * sizeof(float));
     float *wq = (float *)malloc((size_t)(H + CH) * sizeof(float));
+    float *fi = (float *)malloc((size_t)CH * sizeof(float));
+    float *fq = (float *)malloc((size_t)CH * sizeof(float));
     memcpy(wi, st->hist_i, H * sizeof(float));
     memcpy(wq, st->hist_q, H * sizeof(float));
     float *bs = st->bq_state;
@@ -510,12 +532,27 @@ void orc_chain_f32(const orc_chain_f32_cfg *cfg, orc_chain_f32_state *st, const 
             wi[H + i] = xf * cfg->osc_q[ph];
             wq[H + i] = xf * cfg->osc_i[ph];
         }
-        for (uint32_t i = 0; i < len; i++) {
+        /* the FIR pair, ORC_FB outputs side by side (see orc_fir_f32: every output's own sum keeps its order and roundings) */
+        uint32_t i0 = 0;
+        for (; i0 + ORC_FB <= len; i0 += ORC_FB) {
+            float ai[ORC_FB], aq[ORC_FB];
+            for (uint32_t j = 0; j < ORC_FB; j++) { ai[j] = 0.0f; aq[j] = 0.0f; }
+            for (uint32_t k = 0; k < N; k++) {
+                const float ci = cfg->coeffs_i[k], cq = cfg->coeffs_q[k];
+                for (uint32_t j = 0; j < ORC_FB; j++) { ai[j] += wi[i0 + j + k] * ci; aq[j] += wq[i0 + j + k] * cq; }
+            }
+            for (uint32_t j = 0; j < ORC_FB; j++) { fi[i0 + j] = ai[j]; fq[i0 + j] = aq[j]; }
+        }
+        for (; i0 < len; i0++) {
             float ai = 0.0f, aq = 0.0f;
             for (uint32_t k = 0; k < N; k++) {
-                ai += wi[i + k] * cfg->coeffs_i[k];
-                aq += wq[i + k] * cfg->coeffs_q[k];
+                ai += wi[i0 + k] * cfg->coeffs_i[k];
+                aq += wq[i0 + k] * cfg->coeffs_q[k];
             }
+            fi[i0] = ai; fq[i0] = aq;
+        }
+        for (uint32_t i = 0; i < len; i++) {
+            const float ai = fi[i], aq = fq[i];
             float d;
             switch (cfg->mode) {
             case ORC_LSB: d = ai - aq; break;
@@ -537,7 +574,7 @@ void orc_chain_f32(const orc_chain_f32_cfg *cfg, orc_chain_f32_state *st, const 
     memcpy(st->hist_i, wi, H * sizeof(float));
     memcpy(st->hist_q, wq, H * sizeof(float));
     st->n0 += n;
-    free(wi); free(wq);
+    free(wi); free(wq); free(fi); free(fq);
 }
 
 int orc_chain_f32_batch(const orc_chain_f32_cfg *cfg, const int32_t *mode_per_channel,

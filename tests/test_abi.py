@@ -17,9 +17,13 @@ import orclib  # noqa: E402
 
 
 def declared_functions():
-    src = open(os.path.join(ROOT, "include", "msdr.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(msdr_[a-zA-Z0-9_]+)\s*\(", src)))
+    names = set()
+    for header in ("msdr.h", "msdr_cmsis.h"):
+        src = open(os.path.join(ROOT, "include", header)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("#"))      # macro lines are not declarations
+        names |= set(re.findall(r"\b(msdr_[a-zA-Z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -32,7 +36,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_no_oracle_or_reference_linked_into_product():
     out = subprocess.check_output(["nm", "-D", msdr.LIB_PATH]).decode()
-    assert "orc_" not in out and "arm_fir" not in out
+    assert "orc_" not in out and not re.search(r"\b[TtWw] arm_", out)          # (msdr_arm_* are the library's own CMSIS-signature shims)
     ldd = subprocess.check_output(["ldd", msdr.LIB_PATH]).decode()
     assert "liboracle" not in ldd and "msdr_ref" not in ldd
     for root, _, files in os.walk(os.path.join(ROOT, "minimal-sdr_amd")):
@@ -40,6 +44,28 @@ def test_no_oracle_or_reference_linked_into_product():
             if f.endswith((".hip", ".hiph", ".cpp", ".h", ".py")):
                 text = open(os.path.join(root, f)).read()
                 assert "liboracle" not in text and "msdr_oracle" not in text and "orclib" not in text, f
+
+
+class ArmFirQ15(C.Structure):          # include/msdr_cmsis.h = arm_math.h:1027-1032
+    _fields_ = [("numTaps", C.c_uint16), ("pState", C.c_void_p), ("pCoeffs", C.c_void_p)]
+
+
+def test_cmsis_shim_init_contract_without_a_device():
+    """msdr_arm_fir_init_q15 keeps arm_fir_init_q15's contract (arm_fir_init_q15.c:93-109): odd numTaps -> ARGUMENT_ERROR and the
+    instance untouched; otherwise the three fields are bound and numTaps + blockSize state samples cleared.  Without a bound
+    context there is nothing to run on, and the status says so (no CPU path)."""
+    lib = msdr.load_library()
+    lib.msdr_arm_fir_init_q15.argtypes = [C.c_void_p, C.c_uint16, C.c_void_p, C.c_void_p, C.c_uint32]
+    assert lib.msdr_cmsis_bind(None, 0) == 0
+    S = ArmFirQ15(7, 1234, 5678)
+    coef = np.arange(1, 103, dtype=np.int16)
+    state = np.full(102 + 128 + 4, 77, np.int16)
+    assert lib.msdr_arm_fir_init_q15(C.byref(S), 101, coef.ctypes.data, state.ctypes.data, 128) == -1
+    assert (S.numTaps, S.pState, S.pCoeffs) == (7, 1234, 5678) and (state == 77).all()
+    assert lib.msdr_arm_fir_init_q15(C.byref(S), 102, coef.ctypes.data, state.ctypes.data, 128) == -1      # no context bound
+    assert (S.numTaps, S.pState, S.pCoeffs) == (102, state.ctypes.data, coef.ctypes.data)
+    assert (state[:230] == 0).all() and (state[230:] == 77).all()
+    lib.msdr_arm_fir_fast_q15(C.byref(S), None, None, 128)          # unknown instance: returns, nothing to do
 
 
 def test_designer_fir_matches_golden(golden):

@@ -17,7 +17,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kTile = 1024;      // outputs per wave and iteration
 
-// MODE 0: 54 x 32x32x16; MODE 1: 108 x 16x16x32 (four accumulators); IO: stream 4 KB in / 4 KB out per iteration; MFMA: issue the products
+// MODE 0: 54 x 32x32x16 on one accumulator; MODE 1: 108 x 16x16x32 (four accumulators); MODE 2 / 3: 54 x 32x32x16 alternating between
+// two / three independent accumulators (summed at the end); IO: stream 4 KB in / 4 KB out per iteration; MFMA: issue the products
 template <int MODE, bool IO, bool MFMA>
 __global__ __launch_bounds__(256) void ceiling_kernel(const float *__restrict__ x, float *__restrict__ y, const _Float16 *__restrict__ ops,
                                                       int iters, long long *__restrict__ clk)
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void ceiling_kernel(const float *__restrict__ 
         a[i] = *reinterpret_cast<const f16x8 *>(ops + ((i * 64 + lane) * 8));
         b[i] = *reinterpret_cast<const f16x8 *>(ops + ((6 + i) * 64 + lane) * 8);
     }
-    f32x16 acc32 = (f32x16)(0.0f);
+    f32x16 acc32 = (f32x16)(0.0f), acc32b = (f32x16)(0.0f), acc32c = (f32x16)(0.0f);
     f32x4 acc16[4] = {(f32x4)(0.0f), (f32x4)(0.0f), (f32x4)(0.0f), (f32x4)(0.0f)};
     const float *xs = x + wave * (long long)iters * kTile;
     float *ys = y + wave * (long long)iters * kTile;
@@ -57,6 +58,23 @@ __global__ __launch_bounds__(256) void ceiling_kernel(const float *__restrict__ 
                     acc32 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(s + 2) % 6], b[(s + 3) % 6], acc32, 0, 0, 0);
                     acc32 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(s + 4) % 6], b[(s + 5) % 6], acc32, 0, 0, 0);
                 }
+            } else if constexpr (MODE == 2) {
+#pragma unroll
+                for (int s = 0; s < 18; s += 2) {
+                    acc32 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % 6], b[(s + 1) % 6], acc32, 0, 0, 0);
+                    acc32b = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(s + 1) % 6], b[(s + 2) % 6], acc32b, 0, 0, 0);
+                    acc32 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(s + 2) % 6], b[(s + 3) % 6], acc32, 0, 0, 0);
+                    acc32b = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(s + 3) % 6], b[(s + 4) % 6], acc32b, 0, 0, 0);
+                    acc32 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(s + 4) % 6], b[(s + 5) % 6], acc32, 0, 0, 0);
+                    acc32b = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(s + 5) % 6], b[s % 6], acc32b, 0, 0, 0);
+                }
+            } else if constexpr (MODE == 3) {
+#pragma unroll
+                for (int s = 0; s < 18; s++) {
+                    acc32 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s % 6], b[(s + 1) % 6], acc32, 0, 0, 0);
+                    acc32b = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(s + 2) % 6], b[(s + 3) % 6], acc32b, 0, 0, 0);
+                    acc32c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(s + 4) % 6], b[(s + 5) % 6], acc32c, 0, 0, 0);
+                }
             } else {
 #pragma unroll
                 for (int s = 0; s < 9; s++)
@@ -73,7 +91,7 @@ __global__ __launch_bounds__(256) void ceiling_kernel(const float *__restrict__ 
             for (int j = 0; j < 4; j++) {
                 f32x4 v = cur[j];
                 if constexpr (MFMA) {
-                    if constexpr (MODE == 0) v[0] += acc32[j] * 1e-30f; else v[0] += acc16[j][0] * 1e-30f;
+                    if constexpr (MODE == 1) v[0] += acc16[j][0] * 1e-30f; else v[0] += (acc32[j] + acc32b[j] + acc32c[j]) * 1e-30f;
                 }
                 *reinterpret_cast<f32x4 *>(ys + (long long)it * kTile + 4 * (lane + 64 * j)) = v;
             }
@@ -83,7 +101,7 @@ __global__ __launch_bounds__(256) void ceiling_kernel(const float *__restrict__ 
     if (lane == 0) { clk[2 * wave] = c1 - c0; clk[2 * wave + 1] = r1 - r0; }
     if constexpr (!IO) {            // keep the accumulators alive
         float s = 0.0f;
-        if constexpr (MODE == 0) { for (int i = 0; i < 16; i++) s += acc32[i]; } else { for (int q = 0; q < 4; q++) for (int i = 0; i < 4; i++) s += acc16[q][i]; }
+        if constexpr (MODE != 1) { for (int i = 0; i < 16; i++) s += acc32[i] + acc32b[i] + acc32c[i]; } else { for (int q = 0; q < 4; q++) for (int i = 0; i < 4; i++) s += acc16[q][i]; }
         if (s == 123.456f) ys[lane] = s;
     }
 }
@@ -141,6 +159,8 @@ int main(int argc, char **argv)
     for (int wps : {1, 2, 4}) {
         run(ceiling_kernel<0, false, true>, "mfma_only_32x32x16_f16 (54 per 1024 outputs)", wps, tiles, x, y, ops, clk, false);
         run(ceiling_kernel<1, false, true>, "mfma_only_16x16x32_f16 (108 per 1024 outputs)", wps, tiles, x, y, ops, clk, false);
+        run(ceiling_kernel<2, false, true>, "mfma_only_32x32x16_f16, two accumulators alternating", wps, tiles, x, y, ops, clk, false);
+        run(ceiling_kernel<3, false, true>, "mfma_only_32x32x16_f16, three accumulators alternating", wps, tiles, x, y, ops, clk, false);
     }
     for (int wps : {1, 2, 4, 8}) run(ceiling_kernel<0, true, false>, "stream_only", wps, tiles, x, y, ops, clk, true);
     for (int wps : {1, 2, 4}) {

@@ -649,6 +649,39 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
         ysmall = torch.empty((rows, cols), dtype=y.dtype, device=dev)
         t_comp = timed(lambda: pipeline(False), reps=2) / blocks
         t_ovl = timed(lambda: pipeline(True), reps=2) / blocks
+        # the same from C (include/msdr.h msdr_comm_*: RCCL driven by the library, its own stream, event-ordered behind the compute)
+        c_gather = None
+        if args.cdev.type == "cuda":
+            try:
+                uid = [msdr.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                comm = msdr.Comm(ctx, uid[0], rank, world)
+                recv = [torch.empty((world * rows, cols), dtype=y.dtype, device=dev) if rank == 0 else None for _ in range(2)]
+                ybuf = [torch.empty((rows, cols), dtype=y.dtype, device=dev) for _ in range(2)]
+
+                def c_root():
+                    comm.begin(0, part.data_ptr(), m * esz, recv[0].data_ptr() if rank == 0 else None, 0)
+                    comm.wait(0, host_wait=True)
+
+                def c_pipeline():
+                    for k in range(blocks):
+                        comm.wait(k & 1)                       # device-side: the gather that last read this buffer
+                        chain_small.process(xs.data_ptr(), ybuf[k & 1].data_ptr(), cols)
+                        comm.begin(k & 1, ybuf[k & 1].data_ptr(), m * esz, recv[k & 1].data_ptr() if rank == 0 else None, 0)
+                    comm.wait(0, host_wait=True)
+                    comm.wait(1, host_wait=True)
+                t_c = timed(c_root)
+                t_cp = timed(c_pipeline, reps=2) / blocks
+                ok = True
+                if rank == 0:
+                    ok = bool(torch.equal(recv[0][:rows], ybuf[0])) if blocks % 2 == 0 else True
+                comm.close()
+                c_gather = {"op": "msdr_gather_audio_begin / _wait (RCCL send / recv group to rank 0, library-owned stream)",
+                            "ms": round(t_c * 1e3, 3), "GBps_into_root": round((world - 1) * m * esz / t_c / 1e9, 1),
+                            "ms_per_block_with_gather_overlapped": round(t_cp * 1e3, 3),
+                            "gather_time_hidden_frac": round(max(0.0, min(1.0, 1.0 - (t_cp - t_comp) / max(t_c, 1e-9))), 3), "root_received_own_shard": ok}
+            except Exception as e:                           # the torch.distributed figures above stand on their own
+                c_gather = {"error": str(e)[:200]}
         chain_small.close()
         gather = {"audio_dtype": str(y.dtype).replace("torch.", ""), "bytes_per_rank": m * esz, "ranks": world,
                   "rank_devices": args.rank_devices,
@@ -659,7 +692,8 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
                   "overlapped": {"op": "msdr_dist.OverlappedGather: gather(k) to root while block k + 1 is demodulated, two audio buffers",
                                  "block": "%d channels x %d samples per rank" % (rows, cols), "ms_per_block_compute_only": round(t_comp * 1e3, 3),
                                  "ms_per_block_with_gather": round(t_ovl * 1e3, 3),
-                                 "gather_time_hidden_frac": round(max(0.0, min(1.0, 1.0 - (t_ovl - t_comp) / max(t_root, 1e-9))), 3)}}
+                                 "gather_time_hidden_frac": round(max(0.0, min(1.0, 1.0 - (t_ovl - t_comp) / max(t_root, 1e-9))), 3)},
+                  "c_abi": c_gather}
     x_host = x[:first_rows, :keep_x].cpu().numpy() if (rank == 0 and do_cpu) else None
     chain.close()
     del x, y

@@ -97,6 +97,30 @@ int msdr_memcpy_d2d(msdr_ctx *ctx, void *d_dst, const void *d_src, size_t bytes)
 int msdr_memset(msdr_ctx *ctx, void *d_dst, int value, size_t bytes);
 
 /* ======================================================================================
+ * The path's one exchange step: gathering demodulated audio across the GPUs of a node (one
+ * process per GPU; channels are sharded).  RCCL over xGMI, driven from C; RCCL is
+ * loaded on first use (dlopen of librccl.so.1), so a single-GPU application does not need it.
+ *   rank 0: msdr_comm_get_unique_id(id) -> hand the 128 bytes to the other ranks by any host channel
+ *   all   : msdr_comm_create(ctx, id, rank, world, &comm)
+ *   per block k (two or more audio buffers, slot = k % MSDR_GATHER_SLOTS):
+ *           msdr_chain_process(..., audio[k % 2], ...);                    compute on the context's stream
+ *           msdr_gather_audio_begin(comm, slot, audio[k % 2], bytes, d_all, root);   asynchronous, on the communicator's own
+ *                                                                          stream, ordered after the compute queued so far
+ *           ... block k + 1 is demodulated meanwhile ...
+ *           msdr_gather_audio_wait(comm, slot, 0) before anything reuses audio[k % 2] / reads d_all (device-side wait on the
+ *                                                 context's stream; host_wait = 1 blocks the calling thread instead)
+ * root >= 0: only that rank receives, d_recv = [world][local_bytes] in rank order (peers send over one link each);
+ * root < 0 : every rank receives (all-gather).  Every rank passes the same local_bytes (pad the last shard).
+ * ====================================================================================== */
+#define MSDR_GATHER_SLOTS 4
+typedef struct msdr_comm msdr_comm;
+int msdr_comm_get_unique_id(void *id128);
+int msdr_comm_create(msdr_ctx *ctx, const void *id128, int rank, int world, msdr_comm **out);
+int msdr_gather_audio_begin(msdr_comm *comm, int slot, const void *d_local, size_t local_bytes, void *d_recv, int root);
+int msdr_gather_audio_wait(msdr_comm *comm, int slot, int host_wait);
+int msdr_comm_destroy(msdr_comm *comm);
+
+/* ======================================================================================
  * Host-side designers (setup path; pure CPU arithmetic, no device needed).
  * ====================================================================================== */
 /* calc_FIR_coeffs, Minimal-SDR.ino:782-872 (with m_sinc :874-881, Izero :883-899).  Same

@@ -2,6 +2,7 @@
 // Host logic only: argument checks mirroring the reference's error behaviour, coefficient/table
 // preparation, state ownership in HBM, launch geometry.  No CPU compute path exists here: every
 // process/update entry point launches HIP kernels or fails.
+#include <dlfcn.h>
 #include "../../include/msdr.h"
 #include "msdr_kernels.hiph"
 #include "msdr_chain_fold.hiph"
@@ -254,6 +255,141 @@ static int launch_check(const char *what)
 {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MSDR_STATUS_HIP_ERROR, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCCL gather of demodulated audio: the one exchange step of the path, from C.
+// RCCL is loaded on first use (dlopen: a process that already carries an RCCL -- torch's -- shares it; nothing is linked in).
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct RcclUniqueId { char internal[128]; };
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(RcclUniqueId *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.lib ? &api : nullptr;
+    tried = true;
+    for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+        api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (api.lib) break;
+    }
+    if (!api.lib) return nullptr;
+#define MSDR_RCCL_SYM(field, sym) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, sym)); if (!api.field) { api.lib = nullptr; return nullptr; }
+    MSDR_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") MSDR_RCCL_SYM(CommInitRank, "ncclCommInitRank") MSDR_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    MSDR_RCCL_SYM(GroupStart, "ncclGroupStart") MSDR_RCCL_SYM(GroupEnd, "ncclGroupEnd") MSDR_RCCL_SYM(Send, "ncclSend") MSDR_RCCL_SYM(Recv, "ncclRecv")
+    MSDR_RCCL_SYM(AllGather, "ncclAllGather") MSDR_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef MSDR_RCCL_SYM
+    return &api;
+}
+constexpr int kRcclChar = 0;             // ncclInt8 / ncclChar: the audio travels as bytes, whatever its sample type
+}  // namespace
+
+struct msdr_comm {
+    msdr_ctx *ctx;
+    RcclApi *api;
+    void *comm;
+    int rank, world;
+    hipStream_t stream;                  // the gathers' own stream: they overlap the next block's kernels on the context's stream
+    hipEvent_t ready[MSDR_GATHER_SLOTS], done[MSDR_GATHER_SLOTS];
+    bool pending[MSDR_GATHER_SLOTS];
+};
+#define RCCL_TRY(call) do { int r_ = (call); if (r_ != 0) return fail(MSDR_STATUS_HIP_ERROR, "%s: %s", #call, C->api->GetErrorString(r_)); } while (0)
+
+extern "C" int msdr_comm_get_unique_id(void *id128)
+{
+    RcclApi *api = rccl_api();
+    if (!api) return fail(MSDR_STATUS_NO_DEVICE, "librccl.so.1 could not be loaded");
+    if (!id128) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null id");
+    RcclUniqueId id;
+    if (int r = api->GetUniqueId(&id)) return fail(MSDR_STATUS_HIP_ERROR, "ncclGetUniqueId: %s", api->GetErrorString(r));
+    memcpy(id128, &id, sizeof id);
+    return 0;
+}
+extern "C" int msdr_comm_create(msdr_ctx *ctx, const void *id128, int rank, int world, msdr_comm **out)
+{
+    if (!out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "out is null");
+    *out = nullptr;
+    if (int rc = bind(ctx)) return rc;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad communicator arguments");
+    RcclApi *api = rccl_api();
+    if (!api) return fail(MSDR_STATUS_NO_DEVICE, "librccl.so.1 could not be loaded");
+    msdr_comm *C = new (std::nothrow) msdr_comm();
+    if (!C) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
+    C->ctx = ctx; C->api = api; C->comm = nullptr; C->rank = rank; C->world = world; C->stream = nullptr;
+    for (int k = 0; k < MSDR_GATHER_SLOTS; k++) { C->ready[k] = C->done[k] = nullptr; C->pending[k] = false; }
+    RcclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    if (int r = api->CommInitRank(&C->comm, world, id, rank)) { delete C; return fail(MSDR_STATUS_HIP_ERROR, "ncclCommInitRank: %s", api->GetErrorString(r)); }
+    hipError_t e = hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking);
+    for (int k = 0; k < MSDR_GATHER_SLOTS && e == hipSuccess; k++) {
+        e = hipEventCreateWithFlags(&C->ready[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&C->done[k], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) { msdr_comm_destroy(C); return fail(MSDR_STATUS_HIP_ERROR, "communicator stream / events: %s", hipGetErrorString(e)); }
+    *out = C;
+    return 0;
+}
+extern "C" int msdr_gather_audio_begin(msdr_comm *C, int slot, const void *d_local, size_t local_bytes, void *d_recv, int root)
+{
+    if (!C || slot < 0 || slot >= MSDR_GATHER_SLOTS) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad communicator / slot");
+    if (int rc = bind(C->ctx)) return rc;
+    if (root >= C->world) return fail(MSDR_STATUS_ARGUMENT_ERROR, "root out of range");
+    const bool receives = root < 0 || root == C->rank;
+    if (!d_local || (receives && !d_recv)) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
+    // the audio of this block is whatever the context's stream has queued so far
+    HIP_TRY(hipEventRecord(C->ready[slot], C->ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(C->stream, C->ready[slot], 0));
+    if (local_bytes) {
+        if (root < 0) RCCL_TRY(C->api->AllGather(d_local, d_recv, local_bytes, kRcclChar, C->comm, C->stream));
+        else {
+            // gather to one rank: every peer sends its shard over its own link, the root posts one receive per peer (one group)
+            RCCL_TRY(C->api->GroupStart());
+            int r = 0;
+            if (C->rank == root) {
+                for (int peer = 0; peer < C->world && r == 0; peer++)
+                    if (peer != root) r = C->api->Recv((char *)d_recv + (size_t)peer * local_bytes, local_bytes, kRcclChar, peer, C->comm, C->stream);
+            } else r = C->api->Send(d_local, local_bytes, kRcclChar, root, C->comm, C->stream);
+            const int r2 = C->api->GroupEnd();
+            if (r || r2) return fail(MSDR_STATUS_HIP_ERROR, "RCCL gather: %s", C->api->GetErrorString(r ? r : r2));
+            if (C->rank == root) HIP_TRY(hipMemcpyAsync((char *)d_recv + (size_t)root * local_bytes, d_local, local_bytes, hipMemcpyDeviceToDevice, C->stream));
+        }
+    }
+    HIP_TRY(hipEventRecord(C->done[slot], C->stream));
+    C->pending[slot] = true;
+    return 0;
+}
+extern "C" int msdr_gather_audio_wait(msdr_comm *C, int slot, int host_wait)
+{
+    if (!C || slot < 0 || slot >= MSDR_GATHER_SLOTS) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad communicator / slot");
+    if (int rc = bind(C->ctx)) return rc;
+    if (!C->pending[slot]) return 0;
+    if (host_wait) HIP_TRY(hipEventSynchronize(C->done[slot]));
+    else HIP_TRY(hipStreamWaitEvent(C->ctx->stream, C->done[slot], 0));     // later work on the context's stream may reuse the buffers
+    C->pending[slot] = false;
+    return 0;
+}
+extern "C" int msdr_comm_destroy(msdr_comm *C)
+{
+    if (!C) return 0;
+    (void)bind(C->ctx);
+    if (C->stream) (void)hipStreamSynchronize(C->stream);
+    for (int k = 0; k < MSDR_GATHER_SLOTS; k++) { if (C->ready[k]) hipEventDestroy(C->ready[k]); if (C->done[k]) hipEventDestroy(C->done[k]); }
+    if (C->comm) (void)C->api->CommDestroy(C->comm);
+    if (C->stream) (void)hipStreamDestroy(C->stream);
+    delete C;
     return 0;
 }
 

@@ -580,3 +580,42 @@ class Chain(_Instance):
         ms, n = C.c_double(0), C.c_uint64(0)
         _ck(self.ctx.lib.msdr_chain_get_kernel_time(self.h, C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
+
+
+GATHER_SLOTS = 4
+
+
+def comm_unique_id():
+    """128 opaque bytes made by rank 0 (ncclGetUniqueId); pass them to the other ranks by any host channel."""
+    buf = C.create_string_buffer(128)
+    _ck(load_library().msdr_comm_get_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """msdr_comm_*: the RCCL gather of demodulated audio, driven from C (include/msdr.h)."""
+
+    def __init__(self, ctx, unique_id, rank, world):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        h = _p()
+        _ck(ctx.lib.msdr_comm_create(ctx.h, C.c_char_p(unique_id), int(rank), int(world), C.byref(h)))
+        self.h = h
+
+    def begin(self, slot, d_local_ptr, local_bytes, d_recv_ptr, root):
+        _ck(self.ctx.lib.msdr_gather_audio_begin(self.h, int(slot), _p(d_local_ptr), C.c_size_t(local_bytes),
+                                                 _p(d_recv_ptr) if d_recv_ptr else None, int(root)))
+
+    def wait(self, slot, host_wait=False):
+        _ck(self.ctx.lib.msdr_gather_audio_wait(self.h, int(slot), int(host_wait)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            if getattr(self.ctx, "h", None):
+                self.ctx.lib.msdr_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

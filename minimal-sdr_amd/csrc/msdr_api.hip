@@ -1614,6 +1614,7 @@ struct msdr_chain {
     // wave-stream variant (msdr_chain_mfw.hiph): waves per workgroup, resident waves per CU, unit table and its cache key
     uint32_t flags;
     int mfw_nw, mfw_waves_per_cu;
+    bool mf_fr;                                           // full-rate layout (msdr_chain_mfw.hiph): any 128-periodic oscillator table, mixer products staged as two streams
     float *d_bq_state_alt;
     float *d_mw_iir;                  // folded-IIR constants (MwIirConsts) or null
     bool mfw_ssb_fold, mfw_am_fold;   // cascade as matrix products for SSB tables / envelope tables
@@ -1847,7 +1848,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         if (!rc) rc = dzalloc(ctx, (size_t)c->channels * kBqStateFloats, &c->d_bq_state);
     }
     // ---- tap folding (F32): oscillator period, folded tables, per-channel folded-set index ----------
-    c->fold_P = 0; c->fold_fs4_exact = false; c->mf_P = 0;
+    c->fold_P = 0; c->fold_fs4_exact = false; c->mf_P = 0; c->mf_fr = false;
     if (!rc && f32 && !(cfg->flags & MSDR_CHAIN_NO_TAP_FOLDING)) {
         std::vector<double> oc, os;                       // one period of cos / sin
         if (cfg->mixer == MSDR_MIXER_FS4) { oc = {1, 0, -1, 0}; os = {0, 1, 0, -1}; }
@@ -1867,6 +1868,11 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
             }
         }
         c->mf_P = (int)oc.size();
+        // no short period: every AudioEffectFreqConv table still repeats with the block (128 entries, freq_conv.cpp:67-103) -- the
+        // matrix-core kernel then stages the two mixer products as full-rate streams and runs both FIRs over every sample
+        // (up to 247 taps: from 248 on the overlap-save FFT kernel takes any table at a cost that does not double with a second stream)
+        c->mf_fr = oc.empty() && cfg->mixer == MSDR_MIXER_NCO && cfg->osc_len > 0 && (128 % cfg->osc_len) == 0 && c->ntaps < 248;
+        if (c->mf_fr) c->mf_P = 1;                             // one table per (tap set, flavour): the oscillator is not in it
         if (oc.size() > 4) oc.clear();                         // no VALU fold tables beyond period 4
         if (!oc.empty()) {
             const int P = (int)oc.size();
@@ -1915,7 +1921,10 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->mf_ok = false;
     if (!rc && f32 && c->mf_P > 0 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && mf_halo((int)(c->ntaps + 2 * c->nstages)) <= 2048) {
         // SSB tables carry the cascade's numerator C(z) = prod (b0 + b1 z^-1 + b2 z^-2): the FIR grows by 2 taps per section
-        const int P = c->mf_P, N = (int)c->ntaps, NF = N + 2 * (int)c->nstages, H = mf_halo(NF), J = H / 32 + 1, KI = H + 32;
+        const bool fr = c->mf_fr;
+        // (full rate: the window is handled as if it were interleaved I0 Q0 I1 Q1 ..: "even" positions = the I stream, "odd" = the Q
+        //  stream, twice as many of them, so that the run search and the fragment emission below serve both layouts)
+        const int P = c->mf_P, N = (int)c->ntaps, NF = N + 2 * (int)c->nstages, H = mf_halo(NF), KI = H + 32, KIv = fr ? 2 * KI : KI, J = KIv / 32;
         std::vector<double> cnum(1, 1.0);
         for (uint32_t st = 0; st < c->nstages; st++) {
             std::vector<double> nx(cnum.size() + 2, 0.0);
@@ -1925,13 +1934,14 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         }
         std::vector<double> oc(P), os(P);
         if (cfg->mixer == MSDR_MIXER_FS4) { const double c4[4] = {1, 0, -1, 0}, s4[4] = {0, 1, 0, -1}; for (int k = 0; k < 4; k++) { oc[k] = c4[k]; os[k] = s4[k]; } }
+        else if (fr) { oc[0] = 1.0; os[0] = 1.0; }
         else for (int k = 0; k < P; k++) { oc[k] = ((const float *)cfg->osc_q)[k]; os[k] = ((const float *)cfg->osc_i)[k]; }
         struct Tab { MfmaTableHeader h; std::vector<_Float16> frags; };
         std::vector<Tab> tabs((size_t)c->tapsets * 3 * P);
         int bsteps = 0;
         const bool ok = true;
         std::vector<double> M[2];
-        M[0].resize((size_t)KI * 32); M[1].resize((size_t)KI * 32);
+        M[0].resize((size_t)KIv * 32); M[1].resize((size_t)KIv * 32);
         std::vector<double> di(NF), dq(NF), fi(NF), fq(NF);
         // ---- folded IIR (wave-stream kernel, SSB tables, 1 or 2 sections): the all-pole cascade's zero-state response inside a
         // 32-sample row is a lower-triangular Toeplitz matrix L (impulse response g); B' = B L^T puts it into the FIR's own matrix
@@ -2057,6 +2067,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         // used to saturate the first rows after the switch).  Bounds in units of in_scale, like smax / emax below.
         double chain_d_bound = 0.0, chain_sig_bound = 0.0, oamp = 0.0;
         for (int k = 0; k < P; k++) oamp = std::max(oamp, std::max(std::fabs(oc[k]), std::fabs(os[k])));
+        if (fr) for (uint32_t k = 0; k < cfg->osc_len; k++) oamp = std::max(oamp, (double)std::max(std::fabs(((const float *)cfg->osc_q)[k]), std::fabs(((const float *)cfg->osc_i)[k])));
         if (iirfold) {
             double cl1 = 0.0, glmax = 0.0;
             for (double cc : cnum) cl1 += std::fabs(cc);
@@ -2092,6 +2103,18 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                     const std::vector<double> &ti = numfold ? fi : di, &tq = numfold ? fq : dq;
                     const int nt = numfold ? NF : N;
                     double maxabs = 0.0;
+                    if (fr) {
+                        // the samples arrive mixed: stream I meets hI, stream Q meets -/+ hQ (SSB: one accumulator) or hQ (envelope: its own)
+                        std::fill(M[0].begin(), M[0].end(), 0.0); std::fill(M[1].begin(), M[1].end(), 0.0);
+                        for (int i = 0; i < KI; i++)
+                            for (int b = 0; b < 32; b++) {
+                                const int delay = H + b - i;
+                                if (delay < 0 || delay >= nt) continue;
+                                if (v == 2) { M[0][(size_t)(2 * i) * 32 + b] = di[delay]; M[1][(size_t)(2 * i + 1) * 32 + b] = dq[delay]; }
+                                else { M[0][(size_t)(2 * i) * 32 + b] = ti[delay]; M[0][(size_t)(2 * i + 1) * 32 + b] = (v == 0 ? -1.0 : 1.0) * tq[delay]; }
+                                maxabs = std::max(maxabs, std::max(std::fabs(v == 2 ? di[delay] : ti[delay]), std::fabs(v == 2 ? dq[delay] : tq[delay])));
+                            }
+                    } else
                     for (int i = 0; i < KI; i++)
                         for (int b = 0; b < 32; b++) {
                             const int delay = H + b - i;
@@ -2107,7 +2130,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                     const bool fold_iir = numfold && iirfold;
                     if (fold_iir) {                                      // B' = B L^T: columns take in the zero-state all-pole response
                         maxabs = 0.0;
-                        for (int i = 0; i < KI; i++) {
+                        for (int i = 0; i < KIv; i++) {
                             double row[32];
                             for (int b2 = 0; b2 < 32; b2++) {
                                 double a = 0.0;
@@ -2134,9 +2157,10 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                         double colmax = 0.0;
                         for (int b = 0; b < 32; b++) {
                             double c0 = 0.0, c1 = 0.0;
-                            for (int i = 0; i < KI; i++) { c0 += std::fabs(M[0][(size_t)i * 32 + b]); c1 += std::fabs(M[1][(size_t)i * 32 + b]); }
+                            for (int i = 0; i < KIv; i++) { c0 += std::fabs(M[0][(size_t)i * 32 + b]); c1 += std::fabs(M[1][(size_t)i * 32 + b]); }
                             colmax = std::max(colmax, std::sqrt(c0 * c0 + c1 * c1));
                         }
+                        if (fr) colmax *= oamp;                                              // the streams carry the oscillator's amplitude
                         const double emax = std::max(32768.0 * colmax, chain_d_bound);      // |envelope| / 2^ex, and whatever another mode's numerator history holds
                         double cl1 = 0.0, smax = 0.0;
                         for (double cc : cnum) cl1 += std::fabs(cc);
@@ -2203,7 +2227,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                 // 4 per SIMD) under the 160 KB of LDS; ties go to the smaller workgroup
                 int best = 0;
                 for (int w = 1; w <= 16; w++) {
-                    const size_t l = mw_lds_bytes(H, bsteps, w);
+                    const size_t l = mw_lds_bytes(H, bsteps, w, fr);
                     if (l > 160 * 1024) break;
                     const int wgs = std::min<int>((int)((160 * 1024) / l), 16 / w);
                     if (wgs * w > best) { best = wgs * w; c->mfw_nw = w; }
@@ -2212,9 +2236,12 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                 if (best > 0) rc = dzalloc(ctx, (size_t)c->channels * kBqStateFloats, &c->d_bq_state_alt);
                 if (!rc && iirfold && !iirc.empty()) rc = upload(ctx, iirc, &c->d_mw_iir);
                 c->mfw_ssb_fold = iirfold && c->d_mw_iir; c->mfw_am_fold = amfold && c->d_mw_iir;
+                // only the wave-stream kernel knows the full-rate layout
+                if (fr && (best <= 0 || (cfg->flags & MSDR_CHAIN_MFMA_WG))) c->mf_ok = false;
             }
         }
     }
+    if (c->mf_fr && !c->mf_ok) { c->mf_fr = false; c->mf_P = 0; }
     if (!rc && f32 && !c->d_fset) {       // per-channel table-set index (tap set x {LSB, USB, AM}), shared by the folded and FFT kernels
         std::vector<int> fs(c->channels);
         for (uint32_t ch = 0; ch < c->channels; ch++) {
@@ -2456,7 +2483,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
 #endif
     }
 
-    const size_t lds = use_mfw ? mw_lds_bytes(c->mf_halo, c->mf_bsteps, c->mfw_nw) : use_mf ? mf_lds_bytes(c->mf_halo, c->mf_bsteps, c->mf_waves) : use_fft ? fft_lds_bytes() : use_fold ? fold_lds_bytes(p.ntaps_pad) : chain_lds_bytes(p.ntaps_pad);
+    const size_t lds = use_mfw ? mw_lds_bytes(c->mf_halo, c->mf_bsteps, c->mfw_nw, c->mf_fr) : use_mf ? mf_lds_bytes(c->mf_halo, c->mf_bsteps, c->mf_waves) : use_fft ? fft_lds_bytes() : use_fold ? fold_lds_bytes(p.ntaps_pad) : chain_lds_bytes(p.ntaps_pad);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && c->events.size() < 8192) {
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -2474,7 +2501,8 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             q.mf_units = c->d_units + (size_t)(part == 0 ? 0 : c->units_wgs_ssb) * c->mfw_nw * 2;
             q.nseg = (int)c->part_nseg[part]; q.seg_len = c->part_seg_len[part]; q.warm = (int)(c->part_nseg[part] > 1 ? warm_tiles * kTile : 0);
             const bool fold = part == 0 ? c->mfw_ssb_fold : c->mfw_am_fold;
-#define MSDR_MFW_LAUNCH(SS, AMF, FO) hipLaunchKernelGGL((chain_mfw_kernel<SS, AMF, FO>), dim3(g), dim3(block), lds, c->ctx->stream, q)
+#define MSDR_MFW_LAUNCH(SS, AMF, FO) do { if (c->mf_fr) hipLaunchKernelGGL((chain_mfw_kernel<SS, AMF, FO, true>), dim3(g), dim3(block), lds, c->ctx->stream, q); \
+                                          else hipLaunchKernelGGL((chain_mfw_kernel<SS, AMF, FO, false>), dim3(g), dim3(block), lds, c->ctx->stream, q); } while (0)
 #define MSDR_MFW_PLAIN(SS) do { if (part == 0) MSDR_MFW_LAUNCH(SS, false, false); else MSDR_MFW_LAUNCH(SS, true, false); } while (0)
 #define MSDR_MFW_FOLDS(SS) do { if (!fold) MSDR_MFW_PLAIN(SS); else if (part == 0) MSDR_MFW_LAUNCH(SS, false, true); else MSDR_MFW_LAUNCH(SS, true, true); } while (0)
             switch (c->nstages) {
@@ -2490,7 +2518,9 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             if (int rc = launch_check("chain_mfw_kernel")) return rc;
         }
         static const char *const names[5] = {"chain_mfw_kernel<0>", "chain_mfw_kernel<1>", "chain_mfw_kernel<2>", "chain_mfw_kernel<3>", "chain_mfw_kernel<4>"};
-        kname = names[c->nstages];
+        static const char *const names_fr[5] = {"chain_mfw_kernel<0> full-rate NCO streams", "chain_mfw_kernel<1> full-rate NCO streams", "chain_mfw_kernel<2> full-rate NCO streams",
+                                                "chain_mfw_kernel<3> full-rate NCO streams", "chain_mfw_kernel<4> full-rate NCO streams"};
+        kname = c->mf_fr ? names_fr[c->nstages] : names[c->nstages];
         std::swap(c->d_bq_state, c->d_bq_state_alt);          // the kernel read bq_state and wrote bq_state_out
 #ifdef MSDR_STAMPS
         if (getenv("MSDR_STAMP_PRINT")) {

@@ -578,9 +578,11 @@ static bool cascade_needs_cmsis_order(const float *coeffs, int stages)
 // par[o] = parity of the mixer phases that feed accumulator o (I, Q); fir_only: one filter over every sample (the FIR stage).
 // ------------------------------------------------------------------------------------------------
 struct QmTables { std::vector<char> blob; int stride = 0, halo = 0, bsteps = 0; std::vector<char> set_ok; };
-static void qm_build_tables(int N, uint32_t tapsets, const int16_t *const *coef_i, const int16_t *const *coef_q, const int par[2], bool fir_only, QmTables &out)
+// fr: full-rate layout -- accumulator o runs over stream o (I, Q) at every sample, the oscillator is not in the tables.
+static void qm_build_tables(int N, uint32_t tapsets, const int16_t *const *coef_i, const int16_t *const *coef_q, const int par[2], bool fir_only, QmTables &out, bool fr = false)
 {
-    const int H = qm_halo(N), NE = (H + 32) / 2, NC = (NE + 31) / 32;      // source-array elements / 32-element chunks
+    const int H = qm_halo(N), NE = fr ? H + 32 : (H + 32) / 2, NC = (NE + 31) / 32;      // source-array elements / 32-element chunks
+    const int SP = fr ? 1 : 2;                                                           // window samples per array element
     struct QTab { Q15MfHeader h; std::vector<int8_t> frags; };
     std::vector<QTab> tabs((size_t)tapsets * 4);
     out.set_ok.assign(tapsets, 1);
@@ -600,9 +602,10 @@ static void qm_build_tables(int N, uint32_t tapsets, const int16_t *const *coef_
                 for (int r = 0; r < (fir_only ? 2 : 1); r++) {
                     // accumulator o is fed by the window samples i whose mixer phase (rot + i) mod 4 has parity par[o]; the FIR stage
                     // takes both parities as two runs of the same accumulator
-                    const int src = fir_only ? r : ((par[o] + 4 - rot) & 1);
-                    // B[e][b] = tap at delay H + b - (2 e + src) (CMSIS keeps the taps time-reversed: delay d is pCoeffs[N - 1 - d])
-                    auto Bv = [&](int e, int b) -> int { const int d = H + b - (2 * e + src); return (d >= 0 && d < N && e < NE) ? (int)cf[o][N - 1 - d] : 0; };
+                    const int src = fr ? o : fir_only ? r : ((par[o] + 4 - rot) & 1);
+                    // B[e][b] = tap at delay H + b - (2 e + src) (CMSIS keeps the taps time-reversed: delay d is pCoeffs[N - 1 - d]);
+                    // full rate: element e is window sample e
+                    auto Bv = [&](int e, int b) -> int { const int d = H + b - (fr ? e : 2 * e + src); return (d >= 0 && d < N && e < NE) ? (int)cf[o][N - 1 - d] : 0; };
                     int jlo = NC, jhi = -1;
                     for (int j = 0; j < NC; j++) {
                         bool any = false;
@@ -632,7 +635,8 @@ static void qm_build_tables(int N, uint32_t tapsets, const int16_t *const *coef_
             bsteps = std::max(bsteps, total);
         }
     }
-    if (bsteps > 0 && qm_lds_bytes(H, bsteps, 1) <= 160 * 1024) {
+    (void)SP;
+    if (bsteps > 0 && qm_lds_bytes(H, bsteps, 1, fr) <= 160 * 1024) {
         const int stride = kQmHdrBytes + bsteps * 2048;
         out.blob.assign((size_t)stride * tabs.size(), 0);
         for (size_t t = 0; t < tabs.size(); t++) {
@@ -1635,6 +1639,7 @@ struct msdr_chain {
     // Q15 matrix-core kernel (msdr_chain_q15mf.hiph): tables per (tap set, phase), channels ordered by tap set
     char *d_qm_tab;
     int qm_stride, qm_halo, qm_bsteps;
+    bool qm_fr;                       // full-rate layout: any 128-periodic freq_conv table (both filters over every sample)
     std::vector<char> qm_set_ok;      // per tap set: table built (every tap < 32640)
     int *d_qm_order;                  // channels grouped by tap set
     std::vector<uint32_t> qm_group_start, qm_group_count;
@@ -1739,7 +1744,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->flags = cfg->flags; c->mfw_nw = 0; c->mfw_waves_per_cu = 0; c->d_bq_state_alt = nullptr; c->d_mw_iir = nullptr; c->d_units = nullptr; c->units_cap = 0;
     c->mode_gen = 1; c->units_mode_gen = 0; c->units_nseg = 0; c->units_wgs = 0; c->units_wgs_ssb = 0; c->mfw_ssb_fold = false; c->mfw_am_fold = false; c->units_tiles = -1;
     c->part_nseg[0] = c->part_nseg[1] = 1; c->part_seg_len[0] = c->part_seg_len[1] = 0;
-    c->d_qm_tab = nullptr; c->d_qm_order = nullptr; c->qm_stride = 0; c->qm_halo = 0; c->qm_bsteps = 0; c->qm_order_gen = 0;
+    c->d_qm_tab = nullptr; c->d_qm_order = nullptr; c->qm_stride = 0; c->qm_halo = 0; c->qm_bsteps = 0; c->qm_order_gen = 0; c->qm_fr = false;
     c->pll = nullptr; c->d_pll_q = nullptr; c->pll_q_cap = 0;
     c->anr = nullptr; c->d_anr_on = nullptr; c->anr_all = 0;
     if (f32) {
@@ -1830,11 +1835,13 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         if (ok && pq >= 0 && pi >= 0 && pq == pi) ok = false;
         if (ok) { if (pq < 0) pq = (pi >= 0) ? 1 - pi : 0; if (pi < 0) pi = 1 - pq; qm_par[0] = pq; qm_par[1] = pi; qm_mixer_ok = true; }
     }
+    // any other table of the node still repeats with the 128-sample block: the full-rate layout (the products are made at staging time)
+    if (!f32 && cfg->mixer == MSDR_MIXER_NCO && !qm_mixer_ok && cfg->osc_len > 0 && (128 % cfg->osc_len) == 0) { qm_mixer_ok = true; c->qm_fr = true; }
     if (!rc && !f32 && qm_mixer_ok && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && qm_halo((int)c->ntaps) <= 512) {
         std::vector<const int16_t *> ci(c->tapsets), cq(c->tapsets);
         for (uint32_t s = 0; s < c->tapsets; s++) { ci[s] = (const int16_t *)cfg->coeffs_i[s]; cq[s] = (const int16_t *)cfg->coeffs_q[s]; }
         QmTables T;
-        qm_build_tables((int)c->ntaps, c->tapsets, ci.data(), cq.data(), qm_par, false, T);
+        qm_build_tables((int)c->ntaps, c->tapsets, ci.data(), cq.data(), qm_par, false, T, c->qm_fr);
         c->qm_set_ok = T.set_ok;
         if (!T.blob.empty()) {
             rc = upload(ctx, T.blob, &c->d_qm_tab);
@@ -2579,19 +2586,22 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             qseg = ((long long)n_samples + qseg_len - 1) / qseg_len;
             nw = 8;
             while (nw > 1 && cnt * qseg < 256LL * nw) nw >>= 1;
-            while (nw > 1 && qm_lds_bytes(c->qm_halo, c->qm_bsteps, nw) > 80 * 1024) nw >>= 1;     // two workgroups per CU
-            const size_t qlds = qm_lds_bytes(c->qm_halo, c->qm_bsteps, nw);
+            while (nw > 1 && qm_lds_bytes(c->qm_halo, c->qm_bsteps, nw, c->qm_fr) > 80 * 1024) nw >>= 1;     // two workgroups per CU
+            const size_t qlds = qm_lds_bytes(c->qm_halo, c->qm_bsteps, nw, c->qm_fr);
             q.mf_nw = nw; q.nseg = (int)qseg; q.seg_len = qseg_len;
             q.fold_period = (int)c->qm_group_start[gi]; q.fold_rot = (int)cnt; q.mf_waves = (int)(gi / 3);
             grid = (unsigned)((cnt * qseg + nw - 1) / nw);
+#define MSDR_QM_LAUNCH(FL) do { if (c->qm_fr) hipLaunchKernelGGL((chain_q15mf_kernel<FL, true>), dim3(grid), dim3(nw * 64), qlds, c->ctx->stream, q); \
+                                else hipLaunchKernelGGL((chain_q15mf_kernel<FL, false>), dim3(grid), dim3(nw * 64), qlds, c->ctx->stream, q); } while (0)
             switch ((int)(gi % 3)) {
-            case 0: hipLaunchKernelGGL(chain_q15mf_kernel<0>, dim3(grid), dim3(nw * 64), qlds, c->ctx->stream, q); break;
-            case 1: hipLaunchKernelGGL(chain_q15mf_kernel<1>, dim3(grid), dim3(nw * 64), qlds, c->ctx->stream, q); break;
-            default: hipLaunchKernelGGL(chain_q15mf_kernel<2>, dim3(grid), dim3(nw * 64), qlds, c->ctx->stream, q); break;
+            case 0: MSDR_QM_LAUNCH(0); break;
+            case 1: MSDR_QM_LAUNCH(1); break;
+            default: MSDR_QM_LAUNCH(2); break;
             }
+#undef MSDR_QM_LAUNCH
             if (int rc = launch_check("chain_q15mf_kernel")) return rc;
         }
-        kname = "chain_q15mf_kernel"; block = (unsigned)nw * 64; nseg = qseg;
+        kname = c->qm_fr ? "chain_q15mf_kernel full-rate NCO streams" : "chain_q15mf_kernel"; block = (unsigned)nw * 64; nseg = qseg;
     }
     else     hipLaunchKernelGGL((chain_kernel<ArithQ15>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p);
     if (int rc = launch_check("chain_kernel")) return rc;

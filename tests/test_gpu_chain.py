@@ -708,7 +708,8 @@ def test_chain_q15_nco_tables_on_matrix_cores(ctx, orc, golden, variant):
             o += m
             if o >= n:
                 break
-        assert chain.info()["kernel"] == (QM if (flags == 0 and variant != "period8") else VALU)
+        # (period 8 is not the fs/4 special case: it takes the full-rate layout of the same kernel)
+        assert chain.info()["kernel"] == (VALU if flags else QM + " full-rate NCO streams" if variant == "period8" else QM)
         for c in range(ch):
             assert np.array_equal(got[c], orc.chain_q15(x[c], modes[c], hi, hq, mixer=1, osc_i=oi, osc_q=oq)), (variant, flags, c)
 
@@ -874,3 +875,47 @@ def test_chain_f32_any_freq_conv_table_on_matrix_cores(ctx, orc, kind, stages):
     assert "full-rate" in chain.info()["kernel"], chain.info()["kernel"]
     for c in range(ch):
         assert rel_rms(got[c], want[c]) < TOL, (kind, stages, c, rel_rms(got[c], want[c]))
+
+
+@pytest.mark.parametrize("kind", ["p3", "p5", "p64", "p128", "drift", "fullscale"])
+def test_chain_q15_any_freq_conv_table_on_matrix_cores(ctx, orc, golden, kind):
+    """The Q15 chain with AudioEffectFreqConv tables that are NOT the fs/4 special case: the tables repeat with the 128-sample block
+    whatever is in them (freq_conv.cpp:67-103), arm_mult_q15 (saturating) is applied when the samples are staged, and both filters
+    run over every sample on the integer matrix cores -- bit-exact, -32768 samples and table entries included, ragged calls,
+    biquad nodes behind, both envelope flavours, and against the vector-ALU kernel."""
+    rng = np.random.default_rng({"p3": 3, "p5": 5, "p64": 64, "p128": 128, "drift": 7, "fullscale": 9}[kind])
+    k = np.arange(128)
+    if kind == "drift":
+        ph = np.cumsum(rng.uniform(0.2, 0.9, 128))
+        oi, oq = np.round(32767 * np.sin(ph)), np.round(29000 * np.cos(ph))
+    elif kind == "fullscale":
+        oi, oq = rng.choice([-32768, 32767, -1, 0, 1, 12345], 128), rng.choice([-32768, 32767, 0, 77], 128)
+    else:
+        P = int(kind[1:])
+        cyc = {3: 1, 5: 2, 64: 9, 128: 37}[P]
+        oi, oq = np.round(32767 * np.sin(2 * np.pi * cyc * k / P)), np.round(32767 * np.cos(2 * np.pi * cyc * k / P))
+    oi, oq = oi.astype(np.int16), oq.astype(np.int16)
+    ch, n = 4, 24 * B
+    x = rng.integers(-32768, 32768, (ch, n)).astype(np.int16)
+    x[1, ::5] = -32768
+    hi, hq = golden["taps/FIR_SSB_I_coeffs"], golden["taps/FIR_SSB_Q_coeffs"]
+    modes = np.array([orclib.LSB, orclib.AM, orclib.USB, orclib.CW], np.int32)
+    lp, nt = _ref_nodes(orc)
+    for flags, sqrt_kind in ((0, msdr.SQRT_F32), (0, msdr.SQRT_Q31), (msdr.CHAIN_NO_MFMA, msdr.SQRT_F32)):
+        chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, hi, hq, mixer=msdr.MIXER_NCO, modes=modes, osc_i=oi, osc_q=oq, flags=flags,
+                           sqrt_kind=sqrt_kind, biquad_nodes=[[lp], [nt]])
+        got = np.empty_like(x)
+        o = 0
+        for m in [130, 6, 1026, 2, 2, 128, 4, n]:
+            m = min(m, n - o)
+            dx, dy = ctx.to_device(x[:, o:o + m]), ctx.array((ch, m), np.int16)
+            chain.process(dx, dy, m)
+            got[:, o:o + m] = dy.download()
+            o += m
+            if o >= n:
+                break
+        assert ("full-rate" in chain.info()["kernel"]) == (flags == 0), chain.info()["kernel"]
+        for c in range(ch):
+            want = orc.chain_q15(x[c], modes[c], hi, hq, mixer=1, osc_i=oi, osc_q=oq, sqrt_kind=sqrt_kind,
+                                 biquads=[orc.biquad_teensy_new([lp]), orc.biquad_teensy_new([nt])])
+            assert np.array_equal(got[c], want), (kind, flags, sqrt_kind, c)

@@ -15,6 +15,7 @@
 #include "msdr_chain_q15mf.hiph"
 #include "msdr_fir_f32mf.hiph"
 #include "msdr_fir_f32tr.hiph"
+#include "msdr_chain_amtr.hiph"
 #include "msdr_design.h"
 
 #include <algorithm>
@@ -1618,6 +1619,7 @@ struct msdr_chain {
     // wave-stream variant (msdr_chain_mfw.hiph): waves per workgroup, resident waves per CU, unit table and its cache key
     uint32_t flags;
     int mfw_nw, mfw_waves_per_cu;
+    char *d_at_tab; int at_ns, at_stride, at_nw;          // envelope channels with the taps in registers (msdr_chain_amtr.hiph), or null
     bool mf_fr;                                           // full-rate layout (msdr_chain_mfw.hiph): any 128-periodic oscillator table, mixer products staged as two streams
     float *d_bq_state_alt;
     float *d_mw_iir;                  // folded-IIR constants (MwIirConsts) or null
@@ -1667,7 +1669,7 @@ static void chain_free(msdr_chain *c)
     hipFree(c->d_hist[0]); hipFree(c->d_hist[1]); hipFree(c->d_bq); hipFree(c->d_bq_state);
     hipFree(c->d_ftaps); hipFree(c->d_fset); hipFree(c->d_bq_fold);
     hipFree(c->d_fft_h); hipFree(c->d_fft_tw); hipFree(c->d_bq_fft); hipFree(c->d_mf_tab); hipFree(c->d_bq_mf); hipFree(c->d_bq_mf32);
-    hipFree(c->d_bq_state_alt); hipFree(c->d_units); hipFree(c->d_mw_iir); hipFree(c->d_qm_tab); hipFree(c->d_qm_order);
+    hipFree(c->d_bq_state_alt); hipFree(c->d_units); hipFree(c->d_mw_iir); hipFree(c->d_qm_tab); hipFree(c->d_qm_order); hipFree(c->d_at_tab);
     for (int k = 0; k < 2; k++) if (c->nodes[k]) msdr_biquad_q15_destroy(c->nodes[k]);
     if (c->seq_bq) msdr_biquad_df1_f32_destroy(c->seq_bq);
     if (c->pll) msdr_syncam_destroy(c->pll);
@@ -1744,6 +1746,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->flags = cfg->flags; c->mfw_nw = 0; c->mfw_waves_per_cu = 0; c->d_bq_state_alt = nullptr; c->d_mw_iir = nullptr; c->d_units = nullptr; c->units_cap = 0;
     c->mode_gen = 1; c->units_mode_gen = 0; c->units_nseg = 0; c->units_wgs = 0; c->units_wgs_ssb = 0; c->mfw_ssb_fold = false; c->mfw_am_fold = false; c->units_tiles = -1;
     c->part_nseg[0] = c->part_nseg[1] = 1; c->part_seg_len[0] = c->part_seg_len[1] = 0;
+    c->d_at_tab = nullptr; c->at_ns = 0; c->at_stride = 0; c->at_nw = 0;
     c->d_qm_tab = nullptr; c->d_qm_order = nullptr; c->qm_stride = 0; c->qm_halo = 0; c->qm_bsteps = 0; c->qm_order_gen = 0; c->qm_fr = false;
     c->pll = nullptr; c->d_pll_q = nullptr; c->pll_q_cap = 0;
     c->anr = nullptr; c->d_anr_on = nullptr; c->anr_all = 0;
@@ -2249,6 +2252,54 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         }
     }
     if (c->mf_fr && !c->mf_ok) { c->mf_fr = false; c->mf_P = 0; }
+    // ---- envelope channels with the taps in registers (msdr_chain_amtr.hiph): the exact Fs/4 mixer, both FIRs of every tap set with the
+    // same taps (the reference's AM case, Minimal-SDR.ino:917-924), up to 257 taps; rides on the wave-stream kernel's unit table ----
+    if (!rc && f32 && c->mf_ok && c->mfw_nw > 0 && !c->mf_fr && cfg->mixer == MSDR_MIXER_FS4 && !(cfg->flags & (MSDR_CHAIN_MFMA_WG | MSDR_CHAIN_NO_MFMA)) &&
+        at_steps((int)c->ntaps) <= kAtMaxSteps && c->ntaps >= 2 && !getenv("MSDR_NO_AMTR") &&
+        // where it wins (profiles/r02/am_matrix.txt: 256 taps with 0 / 1 biquad sections: 7 - 11 % faster than the wave-stream kernel; shorter
+        // filters or 2+ sections: equal or slower, the other kernel runs the cascade on the matrix cores).  MSDR_AMTR=1 forces it (tests).
+        ((at_steps((int)c->ntaps) == kAtMaxSteps && c->nstages <= 1) || getenv("MSDR_AMTR"))) {
+        bool same = true;
+        for (uint32_t s2 = 0; s2 < c->tapsets && same; s2++)
+            same = memcmp(cfg->coeffs_i[s2], cfg->coeffs_q[s2], (size_t)c->ntaps * sizeof(float)) == 0;
+        if (same) {
+            const int N = (int)c->ntaps, H = at_halo(N), ns = at_steps(N);
+            const size_t stride = at_table_bytes(ns);
+            std::vector<char> blob(stride * c->tapsets, 0);
+            for (uint32_t s2 = 0; s2 < c->tapsets; s2++) {
+                const float *h = (const float *)cfg->coeffs_i[s2];
+                double maxabs = 0.0;
+                for (int k = 0; k < N; k++) maxabs = std::max(maxabs, std::fabs((double)h[k]));
+                int ex = 0;
+                if (maxabs > 0) { (void)std::frexp(maxabs, &ex); ex = 14 - ex; }             // maxabs 2^ex in [2^13, 2^14)
+                AmTrHeader hd;
+                memset(&hd, 0, sizeof hd);
+                hd.ns = ns; hd.post = (float)((double)c->in_scale / std::ldexp(1.0, ex));
+                memcpy(blob.data() + s2 * stride, &hd, sizeof hd);
+                // g[d] = h_by_delay[d] j^-d: gR = h {1,0,-1,0}[d mod 4] (even delays), gI = h {0,-1,0,1}[d mod 4] (odd delays);
+                // arm_fir keeps its taps time-reversed: delay d is pCoeffs[N - 1 - d]
+                auto gR = [&](int d) -> double { return (d >= 0 && d < N && !(d & 1)) ? (double)h[N - 1 - d] * ((d & 2) ? -1.0 : 1.0) : 0.0; };
+                auto gI = [&](int d) -> double { return (d >= 0 && d < N && (d & 1)) ? (double)h[N - 1 - d] * ((d & 2) ? 1.0 : -1.0) : 0.0; };
+                _Float16 *tf = reinterpret_cast<_Float16 *>(blob.data() + s2 * stride + kAtHdrBytes);
+                for (int m = 0; m < 3; m++)
+                    for (int st = 0; st < ns; st++)
+                        for (int l = 0; l < 64; l++)
+                            for (int jj = 0; jj < 8; jj++) {
+                                const int ap = l & 15, kp = 32 * st + 8 * (l >> 4) + jj;
+                                const double v = (m == 0 ? gR(H + 2 * ap - 2 * kp) : m == 1 ? gI(H + 2 * ap - 2 * kp - 1) : gI(H + 2 * ap - 2 * kp + 1)) * std::ldexp(1.0, ex);
+                                const _Float16 vh = (_Float16)v;
+                                const size_t o = ((size_t)(m * ns + st) * 2) * 512 + l * 8 + jj;
+                                tf[o] = vh; tf[o + 512] = (_Float16)(v - (double)vh);
+                            }
+            }
+            int nw = 8;
+            while (nw > 1 && at_lds_bytes(ns, nw) > 160 * 1024) nw--;
+            if (at_lds_bytes(ns, nw) <= 160 * 1024) {
+                rc = upload(ctx, blob, &c->d_at_tab);
+                c->at_ns = ns; c->at_stride = (int)stride; c->at_nw = nw;
+            }
+        }
+    }
     if (!rc && f32 && !c->d_fset) {       // per-channel table-set index (tap set x {LSB, USB, AM}), shared by the folded and FFT kernels
         std::vector<int> fs(c->channels);
         for (uint32_t ch = 0; ch < c->channels; ch++) {
@@ -2508,6 +2559,27 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             q.mf_units = c->d_units + (size_t)(part == 0 ? 0 : c->units_wgs_ssb) * c->mfw_nw * 2;
             q.nseg = (int)c->part_nseg[part]; q.seg_len = c->part_seg_len[part]; q.warm = (int)(c->part_nseg[part] > 1 ? warm_tiles * kTile : 0);
             const bool fold = part == 0 ? c->mfw_ssb_fold : c->mfw_am_fold;
+            if (part == 1 && c->d_at_tab) {
+                // envelope units on the taps-in-registers kernel: the same unit table read with this kernel's own workgroup size
+                ChainParams a = q;
+                const long long entries = (long long)g * c->mfw_nw;
+                a.mf_tab = c->d_at_tab; a.mf_stride = c->at_stride; a.mf_nw = c->at_nw; a.fold_rot = (int)entries;
+                const unsigned ag = (unsigned)((entries + c->at_nw - 1) / c->at_nw);
+                const size_t alds = at_lds_bytes(c->at_ns, c->at_nw);
+#define MSDR_AT_LAUNCH(NS_, SS_) hipLaunchKernelGGL((chain_amtr_kernel<NS_, SS_>), dim3(ag), dim3(c->at_nw * 64), alds, c->ctx->stream, a)
+#define MSDR_AT_STAGES(NS_) switch (c->nstages) { case 0: MSDR_AT_LAUNCH(NS_, 0); break; case 1: MSDR_AT_LAUNCH(NS_, 1); break; case 2: MSDR_AT_LAUNCH(NS_, 2); break; \
+                                                   case 3: MSDR_AT_LAUNCH(NS_, 3); break; default: MSDR_AT_LAUNCH(NS_, 4); break; }
+                switch (c->at_ns) {
+                case 2: MSDR_AT_STAGES(2) break;
+                case 3: MSDR_AT_STAGES(3) break;
+                case 4: MSDR_AT_STAGES(4) break;
+                default: MSDR_AT_STAGES(5) break;
+                }
+#undef MSDR_AT_STAGES
+#undef MSDR_AT_LAUNCH
+                if (int rc2 = launch_check("chain_amtr_kernel")) return rc2;
+                continue;
+            }
 #define MSDR_MFW_LAUNCH(SS, AMF, FO) do { if (c->mf_fr) hipLaunchKernelGGL((chain_mfw_kernel<SS, AMF, FO, true>), dim3(g), dim3(block), lds, c->ctx->stream, q); \
                                           else hipLaunchKernelGGL((chain_mfw_kernel<SS, AMF, FO, false>), dim3(g), dim3(block), lds, c->ctx->stream, q); } while (0)
 #define MSDR_MFW_PLAIN(SS) do { if (part == 0) MSDR_MFW_LAUNCH(SS, false, false); else MSDR_MFW_LAUNCH(SS, true, false); } while (0)
@@ -2528,6 +2600,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         static const char *const names_fr[5] = {"chain_mfw_kernel<0> full-rate NCO streams", "chain_mfw_kernel<1> full-rate NCO streams", "chain_mfw_kernel<2> full-rate NCO streams",
                                                 "chain_mfw_kernel<3> full-rate NCO streams", "chain_mfw_kernel<4> full-rate NCO streams"};
         kname = c->mf_fr ? names_fr[c->nstages] : names[c->nstages];
+        if (c->d_at_tab && c->units_wgs > c->units_wgs_ssb) kname = c->units_wgs_ssb ? "chain_mfw_kernel + chain_amtr_kernel" : "chain_amtr_kernel";
         std::swap(c->d_bq_state, c->d_bq_state_alt);          // the kernel read bq_state and wrote bq_state_out
 #ifdef MSDR_STAMPS
         if (getenv("MSDR_STAMP_PRINT")) {

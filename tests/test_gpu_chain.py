@@ -322,6 +322,67 @@ def test_chain_f32_folded_am_fs4_odd_blocks(ctx, orc, block, engine):
         assert rel_rms(got[c], orc.chain_f32(x[c], orclib.AM, lp, lp, sin4, cos4, bq)) < TOL
 
 
+def _lowpass(ntaps, seed=0):
+    k = np.arange(ntaps) - (ntaps - 1) / 2
+    lp = (np.sinc(2 * (2800 + 100 * seed) / 24000 * k) * np.kaiser(ntaps, 7.0)).astype(np.float32)
+    return (lp / lp.sum()).astype(np.float32)
+
+
+@pytest.mark.parametrize("stages", [0, 1, 2, 4])
+@pytest.mark.parametrize("ntaps", [2, 33, 62, 129, 200, 256, 257])
+def test_chain_f32_envelope_taps_in_registers(ctx, orc, ntaps, stages, monkeypatch):
+    """chain_amtr_kernel (envelope channels, both FIRs the same taps, exact Fs/4 mixer): every step count (2..257 taps) and cascade
+    length, two tap sets, blocks that end inside a tile / at every mixer phase, state carried between the calls.  By default the host
+    picks this kernel only where it measured faster (256-tap class, <= 1 section): MSDR_AMTR=1 makes it take every eligible chain."""
+    monkeypatch.setenv("MSDR_AMTR", "1")
+    rng = np.random.default_rng(500 + ntaps + stages)
+    lps = [_lowpass(ntaps, 0), _lowpass(ntaps, 3)]
+    bq = _f32_biquads(orc, stages)
+    x = rng.integers(-12000, 12001, (3, 9001)).astype(np.int16)
+    tapsets = [0, 1, 0]
+    cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+    want = [orc.chain_f32(x[c], orclib.AM, lps[tapsets[c]], lps[tapsets[c]], sin4, cos4, bq) for c in range(3)]
+    for block in (None, 3073, 1000, 129):
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, 3, lps, lps, mixer=msdr.MIXER_FS4, mode=orclib.AM, tapsets=tapsets, biquad_coeffs=bq)
+        got = run_chain(ctx, chain, x, np.float32, block)
+        assert chain.info()["kernel"] == "chain_amtr_kernel"
+        for c in range(3):
+            assert rel_rms(got[c], want[c]) < TOL, (block, c, rel_rms(got[c], want[c]))
+
+
+def test_chain_f32_envelope_taps_in_registers_default_rule_and_mixed_modes(ctx, orc, monkeypatch):
+    """Without MSDR_AMTR the host takes the kernel for the 256-tap class with at most one section only; SSB channels of the same chain
+    stay on the wave-stream kernel (two launches), and a long block is cut into time segments with a settled cascade."""
+    monkeypatch.delenv("MSDR_AMTR", raising=False)
+    rng = np.random.default_rng(41)
+    lp = _lowpass(256)
+    cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+    for stages, name in ((1, "chain_mfw_kernel + chain_amtr_kernel"), (2, "chain_mfw_kernel<2>")):
+        bq = _f32_biquads(orc, stages)
+        modes = [orclib.AM, orclib.LSB, orclib.AM, orclib.USB]
+        x = rng.integers(-12000, 12001, (4, 6000)).astype(np.int16)
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, 4, lp, lp, mixer=msdr.MIXER_FS4, modes=modes, biquad_coeffs=bq)
+        got = run_chain(ctx, chain, x, np.float32, 2500)
+        assert chain.info()["kernel"] == name
+        for c in range(4):
+            assert rel_rms(got[c], orc.chain_f32(x[c], modes[c], lp, lp, sin4, cos4, bq)) < TOL, (stages, c)
+    n = 1 << 19
+    x = rng.integers(-12000, 12001, (1, n)).astype(np.int16)
+    bq = _f32_biquads(orc, 1)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 1, lp, lp, mixer=msdr.MIXER_FS4, mode=orclib.AM, biquad_coeffs=bq)
+    got = run_chain(ctx, chain, x, np.float32)
+    info = chain.info()
+    assert info["kernel"] == "chain_amtr_kernel" and info["time_segments"] > 1
+    want = orc.chain_f32(x[0], orclib.AM, lp, lp, sin4, cos4, bq)
+    assert rel_rms(got[0], want) < TOL
+    seg = -(-n // info["time_segments"])
+    seg = -(-seg // info["tile"]) * info["tile"]
+    for sgi in range(1, info["time_segments"]):
+        lo = sgi * seg
+        if lo + 64 <= n:
+            assert rel_rms(got[0, lo:lo + 64], want[lo:lo + 64]) < TOL, sgi
+
+
 @pytest.mark.parametrize("engine", ALL_ENGINES)
 def test_chain_f32_am_with_non_fs4_nco(ctx, orc, engine):
     """The packed-fp32 folded kernel does AM only for the exact Fs/4 pattern: a q15-rounded fs/4 table (0.99997)

@@ -1,0 +1,17 @@
+#!/usr/bin/env bash
+# tools/smi_probe.sh <tag> [ENV=VAL ...] -- <bench args>: samples rocm-smi clocks / power while the bench loops
+TAG=$1; shift
+ENVS=()
+while [ "$1" != "--" ]; do ENVS+=("$1"); shift; done; shift
+cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+mkdir -p gpurun_out/r02
+( for e in "${ENVS[@]}"; do export "$e"; done; python3 bench.py "$@" --no-cpu --no-parity --steps ${STEPS:-6000} --warmup 5 > gpurun_out/r02/smi_$TAG.json 2>/dev/null ) &
+BP=$!
+sleep ${WAIT:-5}
+for i in 1 2 3 4; do
+  rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|mclk|fclk|Power" | tr '\n' ' '; echo
+  sleep 0.7
+done
+wait $BP
+python3 -c "
+import json; d=json.load(open('gpurun_out/r02/smi_$TAG.json')); print('$TAG', 'ms', d['ms_per_step'])"

@@ -519,20 +519,28 @@ def parity_windows(wl, info, x, y, q15, torch):
     return wins, L, bounds
 
 
-def chain_parity(wl, info, x, y, q15, torch, orc, orclib):
-    """GPU output against the oracle on parity_windows(); the oracle runs over [lo - preroll, lo + L) restarted on an oscillator
-    period boundary (FIR history and IIR state settle inside the pre-roll) -- tests/test_gpu_fullsize.py:_window_check."""
+def chain_parity_capture(wl, info, x, y, q15, torch):
+    """The parity windows' IF input and GPU audio, copied to the host right after the first pass (small); the oracle runs on them
+    AFTER the timed region, so that the card does not sit idle (and fall to its idle clock) just before the warm-up steps."""
     wins, L, bounds = parity_windows(wl, info, x, y, q15, torch)
-    osc_i, osc_q = wl["osc"] if wl["osc"] else (np.array([0, 1, 0, -1], np.float32), np.array([1, 0, -1, 0], np.float32))
     period = 128 if wl["osc"] else 4
     preroll = 8192
-    worst, checked = 0.0, 0
-    nodes = None
+    cap = []
     for c, lo in wins:
         start = max(0, lo - preroll)
         start -= start % period
-        xs = x[c, start:lo + L].cpu().numpy()
-        got = y[c, lo:lo + L].cpu().numpy()
+        cap.append((c, lo, start, x[c, start:lo + L].cpu().numpy(), y[c, lo:lo + L].cpu().numpy()))
+    return cap, L, bounds, preroll
+
+
+def chain_parity(wl, captured, q15, orc, orclib):
+    """GPU output against the oracle on parity_windows(); the oracle runs over [lo - preroll, lo + L) restarted on an oscillator
+    period boundary (FIR history and IIR state settle inside the pre-roll) -- tests/test_gpu_fullsize.py:_window_check."""
+    cap, L, bounds, preroll = captured
+    osc_i, osc_q = wl["osc"] if wl["osc"] else (np.array([0, 1, 0, -1], np.float32), np.array([1, 0, -1, 0], np.float32))
+    worst, checked = 0.0, 0
+    nodes = None
+    for c, lo, start, xs, got in cap:
         mode = int(wl["modes"][c]) if wl["modes"] is not None else wl["mode"]
         ts = int(wl["tapsets"][c]) if wl["tapsets"] is not None else 0
         if q15:
@@ -547,7 +555,7 @@ def chain_parity(wl, info, x, y, q15, torch, orc, orclib):
             worst = max(worst, float(np.sqrt(((want - got) ** 2).sum() / max((want ** 2).sum(), 1e-300))))
         checked += L
     return {("mismatching_samples" if q15 else "rel_rms_worst"): float("%.3g" % worst), "tolerance": 0 if q15 else 1e-5,
-            "windows": [{"channel": int(c), "start": int(lo), "length": int(L)} for c, lo in wins],
+            "windows": [{"channel": int(c), "start": int(lo), "length": int(L)} for c, lo, _, _, _ in cap],
             "segment_boundaries_covered": [int(b) for b in bounds], "oracle_preroll": preroll, "samples_checked": int(checked)}
 
 
@@ -605,16 +613,21 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
     keep = min(n, 1 << 22)                                     # GPU audio kept for the head comparison with the timed CPU sample
     keep_x = min(n, (1 << 26) if ch == 1 else (1 << 22))       # IF sample handed to the CPU baseline
     gpu_first = None
+    captured = None
     if rank == 0 and (do_cpu or args.parity):
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import orclib
-        parity = chain_parity(wl, info, x, y, q15, torch, orclib.Oracle(), orclib)
+        captured = chain_parity_capture(wl, info, x, y, q15, torch)          # small host copies; the oracle runs after the timed region
         if do_cpu:
-            gpu_first = y[:first_rows, :keep].cpu().numpy()
+            gpu_first = y[:first_rows, :keep].clone()                        # on the device for now
     chain.enable_timing(True)
     dt = timed_steps(args, torch, dev, dist, lambda: chain.process(x.data_ptr(), y.data_ptr(), n), after_warmup=chain.kernel_time)
     kernel_ms, launches = chain.kernel_time()
     chain.enable_timing(False)
+    if captured is not None:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orclib
+        parity = chain_parity(wl, captured, q15, orclib.Oracle(), orclib)
+        if gpu_first is not None:
+            gpu_first = gpu_first.cpu().numpy()
 
     gather = None
     if dist is not None and do_gather:                         # RCCL gather of demodulated audio, timed on its own

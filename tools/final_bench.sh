@@ -14,11 +14,12 @@ except Exception as e:
     print(sys.argv[2], "FAILED", e)
 PY
 }
-run c2
+run c2 --workload c2
 run c3 --workload c3
 run c4 --workload c4
 run c5 --workload c5
-run c2_nomfma --no-mfma
+run c2_nomfma --workload c2 --no-mfma
+run c3_nomfma --workload c3 --no-mfma
 run q15_c3 --arith q15 --workload c3
 run q15_c4 --arith q15 --workload c4
 run q15_c5 --arith q15 --workload c5

@@ -16,6 +16,7 @@ ctx = msdr.Context(0)
 B = 128
 t_end = time.time() + budget
 cases = bad = inherent = 0
+seen = {}
 
 
 def truth64(x, mode, hi, hq, oi, oq, bq):
@@ -70,10 +71,25 @@ while time.time() < t_end:
         mixer = int(rng.integers(0, 2))
         oi = oq = None
         if mixer:
-            a, b, c_, d = [int(v) for v in rng.integers(-32768, 32768, 4)]
-            pat = int(rng.integers(0, 2))
-            q4, i4 = ([a, 0, b, 0], [0, c_, 0, d]) if pat == 0 else ([0, a, 0, b], [c_, 0, d, 0])
-            oq, oi = np.array(q4, np.int16)[np.arange(B) % 4], np.array(i4, np.int16)[np.arange(B) % 4]
+            kind = int(rng.integers(0, 4))
+            if kind < 2:            # the fs/4 pattern (zeros at one parity): the zero-skipping layout
+                a, b, c_, d = [int(v) for v in rng.integers(-32768, 32768, 4)]
+                q4, i4 = ([a, 0, b, 0], [0, c_, 0, d]) if kind == 0 else ([0, a, 0, b], [c_, 0, d, 0])
+                oq, oi = np.array(q4, np.int16)[np.arange(B) % 4], np.array(i4, np.int16)[np.arange(B) % 4]
+            elif kind == 2:         # a sampled oscillator of period 8 .. 128 (full-rate layout), q15-rounded, now and then with full-scale entries
+                P_ = int(rng.choice([8, 16, 32, 64, 128]))
+                k_ = np.arange(B)
+                amp_ = 32767 if rng.integers(0, 2) else int(rng.integers(1000, 32768))
+                oi = np.round(amp_ * np.sin(2 * np.pi * k_ / P_)).astype(np.int16)
+                oq = np.round(amp_ * np.cos(2 * np.pi * k_ / P_)).astype(np.int16)
+                if rng.integers(0, 3) == 0:
+                    oi[rng.integers(0, B, 3)] = -32768; oq[rng.integers(0, B, 3)] = -32768
+            else:                   # an unstructured 128-entry table
+                oi, oq = rng.integers(-32768, 32768, B).astype(np.int16), rng.integers(-32768, 32768, B).astype(np.int16)
+            if ntaps >= 248:
+                ntaps = int(rng.integers(1, 124)) * 2      # (the general-table layouts take < 248 taps; longer ones run the vector-ALU kernel: slow to fuzz)
+                ci = [rng.integers(-amp, amp + 1, ntaps).astype(np.int16) for _ in range(nsets)]
+                cq = [rng.integers(-amp, amp + 1, ntaps).astype(np.int16) for _ in range(nsets)]
         nodes = []
         even_only = False
         if rng.integers(0, 2):
@@ -108,6 +124,7 @@ while time.time() < t_end:
                 print("MISMATCH q15 chain", dict(seed=seed, case=cases, ntaps=ntaps, ch=ch, n=n, mixer=mixer, mode=int(modes[c]), nodes=len(nodes), sk=sk,
                                                   kernel=chain.info()["kernel"], first=int(np.nonzero(got[c] != want)[0][0])))
                 break
+        seen[chain.info()["kernel"]] = seen.get(chain.info()["kernel"], 0) + 1
         chain.close()
     elif which == 1:    # arm_fir_fast_q15 stage
         ntaps = int(rng.integers(1, 257)) * 2
@@ -134,11 +151,13 @@ while time.time() < t_end:
         hq = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
         modes = rng.choice([orclib.AM, orclib.LSB, orclib.USB, orclib.CW], ch).astype(np.int32)
         if (modes == orclib.AM).any() or (modes == orclib.CW).any():
-            hq = hi.copy() if rng.integers(0, 2) else hq
+            hq = hi.copy() if rng.integers(0, 4) else hq
         mixer = int(rng.integers(0, 2))
-        P = int(rng.choice([1, 2, 4, 8, 16, 32, 64]))
+        P = int(rng.choice([1, 2, 4, 8, 16, 32, 64, 128, 0]))
         k = np.arange(B)
-        if mixer:
+        if mixer and P == 0:          # an unstructured table (full-rate layout)
+            oi, oq = rng.uniform(-1, 1, B).astype(np.float32), rng.uniform(-1, 1, B).astype(np.float32)
+        elif mixer:
             oi = (np.round(32767 * np.sin(2 * np.pi * k / P)).astype(np.int16) / 32768.0).astype(np.float32)
             oq = (np.round(32767 * np.cos(2 * np.pi * k / P)).astype(np.int16) / 32768.0).astype(np.float32)
         else:
@@ -153,6 +172,11 @@ while time.time() < t_end:
                 rows.append([c_[0], c_[1], c_[2], -c_[3], -c_[4]])
             bq = np.array(rows, np.float32)
         x = rand_x(ch, n)
+        # envelope channels behind the Fs/4 mixer with hI == hQ: every second case through chain_amtr_kernel whatever the tap count
+        if rng.integers(0, 2):
+            os.environ["MSDR_AMTR"] = "1"
+        else:
+            os.environ.pop("MSDR_AMTR", None)
         chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, hi, hq, mixer=mixer, modes=modes, osc_i=oi if mixer else None, osc_q=oq if mixer else None,
                            biquad_coeffs=bq, time_segments=int(rng.choice([0, 0, 1, 3])))
         got = np.empty((ch, n), np.float32)
@@ -185,6 +209,7 @@ while time.time() < t_end:
                 print("MISMATCH f32 chain", dict(seed=seed, case=cases, ntaps=ntaps, ch=ch, n=n, mixer=mixer, P=P, mode=int(modes[c]), stages=stages, err=err,
                                                   kernel=chain.info()["kernel"]))
                 break
+        seen[chain.info()["kernel"]] = seen.get(chain.info()["kernel"], 0) + 1
         chain.close()
     elif which == 4:    # fp32 chain, msdr_chain_set_mode between calls (FIR history and cascade state carry over; folded-numerator modes are entered / left)
         ntaps = int(rng.integers(2, 200))
@@ -253,5 +278,6 @@ while time.time() < t_end:
         fir.close()
     if cases % 50 == 0:
         print("cases", cases, "bad", bad, flush=True)
+print("kernels exercised by the chain cases:", seen)
 print("fuzz done: %d cases, %d mismatches (seed %d); %d fp32-chain checks beyond the oracle tolerance where the oracle is as far from float64" % (cases, bad, seed, inherent))
 sys.exit(1 if bad else 0)

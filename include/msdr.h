@@ -356,7 +356,8 @@ typedef struct {
 #define MSDR_CHAIN_NO_MFMA 8u        /* never run the FIR on the matrix cores (F32: split-fp16 MFMA kernel; Q15: byte-split i8 MFMA kernel) */
 #define MSDR_CHAIN_FOLD_ANY_PERIOD 64u /* F32, NCO: fold the mixer into the taps (matrix-core kernel) also when the oscillator table's only period is its
                                          own length (8, 16 or 32 samples); a table that repeats within its length with period 1 .. 32 is folded by default */
-#define MSDR_CHAIN_SYNCAM_PLL 32u    /* Q15: SYNCAM channels run the PLL demodulator (.ino:631-688) instead of the AM branch */
+#define MSDR_CHAIN_SYNCAM_PLL 32u    /* SYNCAM channels run the PLL demodulator (.ino:631-688) instead of the AM branch.  Q15: as the reference, on the int16
+                                       FIR outputs.  F32 (an extension): the same loop on the fp32 FIR outputs, audio = corr[0] untruncated */
 #define MSDR_CHAIN_MFMA_WG 16u       /* F32: matrix-core kernel with workgroup tiles (msdr_chain_mfma.hiph) instead of one wave per stream */
 
 typedef struct msdr_chain msdr_chain;
@@ -373,9 +374,12 @@ int msdr_chain_init_fir(msdr_chain *chain);
  * The Teensy biquad NODES of a Q15 chain keep their history (the reference never clears it, filter_biquad.cpp:95-97). */
 int msdr_chain_reset(msdr_chain *chain);
 int msdr_chain_set_mode(msdr_chain *chain, uint32_t channel, int32_t mode, int32_t tapset);
-/* Q15 chains: ANR_on per channel (host array of `channels` values, or NULL: anr_on_all for every channel); the LMS filter
- * then runs between the demodulator and the biquad nodes (Minimal-SDR.ino:702-770).  Its state is created on first use and
- * cleared by msdr_chain_reset() (not by msdr_chain_init_fir()). */
+/* ANR_on per channel (host array of `channels` values, or NULL: anr_on_all for every channel); the LMS filter then runs between
+ * the demodulator and the biquad nodes / cascade (Minimal-SDR.ino:702-770).  Its state is created on first use and cleared by
+ * msdr_chain_reset() (not by msdr_chain_init_fir()).  Q15 chains: as the reference, on the int16 audio.  F32 chains (an
+ * extension): the same statements on the fp32 audio, in the reference's sample units (x 32768 in, / 32768 out), nothing truncated;
+ * such channels (and SYNCAM channels under MSDR_CHAIN_SYNCAM_PLL) are demodulated by an auxiliary pass behind the main kernel --
+ * one lane per channel, serial in time like the reference -- and their cascade restarts when a retune changes the set. */
 int msdr_chain_set_anr(msdr_chain *chain, const int32_t *anr_on, int32_t anr_on_all);
 int msdr_chain_destroy(msdr_chain *chain);
 /* introspection for benchmarks/tests: name of the main kernel variant and launch geometry of the last call */

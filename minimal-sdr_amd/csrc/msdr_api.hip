@@ -1654,6 +1654,20 @@ struct msdr_chain {
     msdr_anr *anr;                    // Q15: LMS notch / noise reduction between demodulator and biquad nodes (msdr_chain_set_anr)
     int *d_anr_on;
     int anr_all;
+    // F32: rows f2 / f3 inside the fp32 chain ("post channels": SYNCAM channels under MSDR_CHAIN_SYNCAM_PLL, channels with the LMS filter
+    // on).  Their FIR outputs come from an auxiliary chain without biquads over the gathered IF rows; PLL, LMS filter and the cascade
+    // (arm_biquad_cascade_df1_f32 stage) run behind it and the result replaces the main kernel's rows.  See chain_post_run().
+    bool f32_pll;
+    std::vector<int> h_anr;           // per channel: 0 off, 1 notch, 2 noise reduction
+    std::vector<float> h_bq;          // 5 * h_bq_stages biquad coefficients as given at creation
+    uint32_t h_bq_stages;
+    uint64_t anr_gen, post_mode_gen, post_anr_gen;
+    msdr_chain *aux;
+    msdr_biquad_df1_f32 *post_bq;
+    int npost, nvirt;
+    int *d_post_ch, *d_post_src, *d_post_pll, *d_post_anr, *d_virt_row;
+    float *d_post_pll_state, *d_post_anr_state;      // [channels][4], [channels][kAnrStateFloats]: indexed by CHANNEL, they survive a retune
+    int16_t *d_aux_x; float *d_aux_y, *d_post_scratch; size_t post_cap_n;
     msdr_chain_info info;
     // optional per-launch timing of the main kernel
     bool timing;
@@ -1662,9 +1676,21 @@ struct msdr_chain {
     uint64_t timed_launches;
 };
 
+static void chain_post_free(msdr_chain *c)
+{
+    if (c->aux) msdr_chain_destroy(c->aux);
+    if (c->post_bq) msdr_biquad_df1_f32_destroy(c->post_bq);
+    c->aux = nullptr; c->post_bq = nullptr;
+    hipFree(c->d_post_ch); hipFree(c->d_post_src); hipFree(c->d_post_pll); hipFree(c->d_post_anr); hipFree(c->d_virt_row);
+    c->d_post_ch = c->d_post_src = c->d_post_pll = c->d_post_anr = c->d_virt_row = nullptr;
+    c->npost = 0; c->nvirt = 0;
+}
+
 static void chain_free(msdr_chain *c)
 {
     if (!c) return;
+    chain_post_free(c);
+    hipFree(c->d_post_pll_state); hipFree(c->d_post_anr_state); hipFree(c->d_aux_x); hipFree(c->d_aux_y); hipFree(c->d_post_scratch);
     hipFree(c->d_taps); hipFree(c->d_osc); hipFree(c->d_mode); hipFree(c->d_tapset);
     hipFree(c->d_hist[0]); hipFree(c->d_hist[1]); hipFree(c->d_bq); hipFree(c->d_bq_state);
     hipFree(c->d_ftaps); hipFree(c->d_fset); hipFree(c->d_bq_fold);
@@ -1716,6 +1742,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         if (int rc = msdr_biquad_df1_f32_create(ctx, (uint8_t)cfg->num_biquad_stages, cfg->biquad_coeffs, cfg->channels, &(*out)->seq_bq)) {
             msdr_chain_destroy(*out); *out = nullptr; return rc;
         }
+        (*out)->h_bq.assign(cfg->biquad_coeffs, cfg->biquad_coeffs + 5 * cfg->num_biquad_stages); (*out)->h_bq_stages = cfg->num_biquad_stages;
         return 0;
     }
 
@@ -1750,6 +1777,11 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->d_qm_tab = nullptr; c->d_qm_order = nullptr; c->qm_stride = 0; c->qm_halo = 0; c->qm_bsteps = 0; c->qm_order_gen = 0; c->qm_fr = false;
     c->pll = nullptr; c->d_pll_q = nullptr; c->pll_q_cap = 0;
     c->anr = nullptr; c->d_anr_on = nullptr; c->anr_all = 0;
+    c->f32_pll = f32 && (cfg->flags & MSDR_CHAIN_SYNCAM_PLL); c->h_bq_stages = 0; c->anr_gen = 1; c->post_mode_gen = 0; c->post_anr_gen = 0;
+    c->aux = nullptr; c->post_bq = nullptr; c->npost = 0; c->nvirt = 0;
+    c->d_post_ch = c->d_post_src = c->d_post_pll = c->d_post_anr = c->d_virt_row = nullptr;
+    c->d_post_pll_state = c->d_post_anr_state = nullptr; c->d_aux_x = nullptr; c->d_aux_y = c->d_post_scratch = nullptr; c->post_cap_n = 0;
+    if (f32 && cfg->num_biquad_stages) { c->h_bq.assign(cfg->biquad_coeffs, cfg->biquad_coeffs + 5 * cfg->num_biquad_stages); c->h_bq_stages = cfg->num_biquad_stages; }
     if (f32) {
         c->h_coef_i.resize(c->tapsets); c->h_coef_q.resize(c->tapsets);
         for (uint32_t s = 0; s < c->tapsets; s++) {
@@ -2385,6 +2417,119 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     return 0;
 }
 
+
+// ---- rows f2 / f3 inside the fp32 chain: the post path (struct msdr_chain) ------------------------------------------------------
+__global__ void post_hist_copy_kernel(const int16_t *__restrict__ src, int16_t *__restrict__ dst, const int *__restrict__ row, int hl_src, int hl_dst)
+{
+    // row v of dst = the newest min(hl_src, hl_dst) history samples of row[v] of src, older entries zero (both "oldest first")
+    const int v = blockIdx.y;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < hl_dst; k += gridDim.x * blockDim.x) {
+        const int back = hl_dst - k;                                  // 1 = newest
+        dst[(long long)v * hl_dst + k] = (back <= hl_src) ? src[(long long)row[v] * hl_src + (hl_src - back)] : (int16_t)0;
+    }
+}
+
+static bool chain_post_wanted(const msdr_chain *c, uint32_t ch, bool *pll, int *anr)
+{
+    *pll = c->f32_pll && c->h_mode[ch] == MSDR_MODE_SYNCAM;
+    *anr = c->h_anr.empty() ? 0 : c->h_anr[ch];
+    return *pll || *anr > 0;
+}
+
+// (re)builds the auxiliary chain and the index tables for the current modes / LMS switches; FIR history and oscillator position are
+// taken over from the main chain, PLL and LMS state are per CHANNEL and persist, the post cascade restarts
+static int chain_post_build(msdr_chain *c)
+{
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    chain_post_free(c);
+    c->post_mode_gen = c->mode_gen; c->post_anr_gen = c->anr_gen;
+    std::vector<int> post_ch, post_src, post_pll, post_anr, virt_row, virt_mode, virt_ts;
+    for (uint32_t ch = 0; ch < c->channels; ch++) {
+        bool pll; int anr;
+        if (!chain_post_wanted(c, ch, &pll, &anr)) continue;
+        post_ch.push_back((int)ch); post_src.push_back((int)virt_row.size()); post_pll.push_back(pll ? 1 : 0); post_anr.push_back(anr);
+        if (pll) {          // I + Q and I - Q: the two sideband flavours of the same filters
+            virt_row.push_back((int)ch); virt_mode.push_back(MSDR_MODE_USB); virt_ts.push_back(c->h_tapset[ch]);
+            virt_row.push_back((int)ch); virt_mode.push_back(MSDR_MODE_LSB); virt_ts.push_back(c->h_tapset[ch]);
+        } else {
+            virt_row.push_back((int)ch); virt_mode.push_back(c->h_mode[ch]); virt_ts.push_back(c->h_tapset[ch]);
+        }
+    }
+    if (post_ch.empty()) return 0;
+    msdr_chain_config a;
+    memset(&a, 0, sizeof a);
+    a.struct_size = sizeof a; a.arith = MSDR_ARITH_F32; a.channels = (uint32_t)virt_row.size(); a.mixer = c->mixer;
+    a.num_taps = c->ntaps; a.num_tapsets = c->tapsets;
+    for (uint32_t ts = 0; ts < c->tapsets; ts++) { a.coeffs_i[ts] = c->h_coef_i[ts].data(); a.coeffs_q[ts] = c->h_coef_q[ts].data(); }
+    a.default_mode = MSDR_MODE_AM; a.mode = virt_mode.data(); a.tapset = virt_ts.data(); a.sqrt_kind = c->sqrt_kind;
+    std::vector<float> oi(c->osc_len), oq(c->osc_len);
+    for (uint32_t k = 0; k < c->osc_len; k++) { oq[k] = (float)c->h_osc[2 * k]; oi[k] = (float)c->h_osc[2 * k + 1]; }
+    if (c->mixer == MSDR_MIXER_NCO) { a.osc_len = c->osc_len; a.osc_i = oi.data(); a.osc_q = oq.data(); }
+    a.in_scale = c->in_scale; a.num_biquad_stages = 0; a.time_segments = 0;
+    a.flags = c->flags & ~(uint32_t)MSDR_CHAIN_SYNCAM_PLL;
+    if (int rc = msdr_chain_create(c->ctx, &a, &c->aux)) return rc;
+    c->aux->phase = c->phase;
+    if (c->h_bq_stages)
+        if (int rc = msdr_biquad_df1_f32_create(c->ctx, (uint8_t)c->h_bq_stages, c->h_bq.data(), (uint32_t)post_ch.size(), &c->post_bq)) return rc;
+    if (int rc = upload(c->ctx, post_ch, &c->d_post_ch)) return rc;
+    if (int rc = upload(c->ctx, post_src, &c->d_post_src)) return rc;
+    if (int rc = upload(c->ctx, post_pll, &c->d_post_pll)) return rc;
+    if (int rc = upload(c->ctx, post_anr, &c->d_post_anr)) return rc;
+    if (int rc = upload(c->ctx, virt_row, &c->d_virt_row)) return rc;
+    c->npost = (int)post_ch.size(); c->nvirt = (int)virt_row.size();
+    if (!c->d_post_pll_state) {
+        if (int rc = dzalloc(c->ctx, (size_t)c->channels * 4, &c->d_post_pll_state)) return rc;
+        std::vector<float> h((size_t)c->channels * kAnrStateFloats, 0.0f);
+        for (uint32_t ch = 0; ch < c->channels; ch++) { h[(size_t)ch * kAnrStateFloats] = 120.0f; h[(size_t)ch * kAnrStateFloats + 1] = 0.001f; }   // .ino:715,:718
+        if (int rc = upload(c->ctx, h, &c->d_post_anr_state)) return rc;
+    }
+    // the auxiliary chain continues the main chain's stream: same raw IF history (the newest samples both keep), same table position
+    hipLaunchKernelGGL(post_hist_copy_kernel, dim3(4, c->nvirt), dim3(256), 0, c->ctx->stream, (const int16_t *)c->d_hist[c->cur],
+                       c->aux->d_hist[c->aux->cur], (const int *)c->d_virt_row, (int)c->hist_len, (int)c->aux->hist_len);
+    return launch_check("post_hist_copy_kernel");
+}
+
+// called by msdr_chain_process (F32) after the main kernel: replaces the rows of the post channels in d_audio
+static int chain_post_run(msdr_chain *c, const int16_t *d_if, float *d_audio, uint64_t n)
+{
+    bool any = c->f32_pll;
+    if (!any) for (int v : c->h_anr) if (v > 0) { any = true; break; }
+    if (!any && !c->aux) return 0;
+    if (c->post_mode_gen != c->mode_gen || c->post_anr_gen != c->anr_gen) if (int rc = chain_post_build(c)) return rc;
+    if (c->npost == 0) return 0;
+    if (n > 0xFFFFFFFFull) return fail(MSDR_STATUS_LENGTH_ERROR, "PLL / LMS channels of an fp32 chain take blocks below 2^32 samples");
+    if (c->post_cap_n < n) {
+        hipFree(c->d_aux_x); hipFree(c->d_aux_y); hipFree(c->d_post_scratch);
+        c->d_aux_x = nullptr; c->d_aux_y = nullptr; c->d_post_scratch = nullptr; c->post_cap_n = 0;
+        HIP_TRY(hipMalloc(&c->d_aux_x, (size_t)c->nvirt * n * sizeof(int16_t)));
+        HIP_TRY(hipMalloc(&c->d_aux_y, (size_t)c->nvirt * n * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->d_post_scratch, (size_t)c->npost * n * sizeof(float)));
+        c->post_cap_n = n;
+    }
+    const unsigned gx = (unsigned)std::min<uint64_t>(64, (n + 255) / 256);
+    hipLaunchKernelGGL(post_gather_rows_kernel, dim3(gx, c->nvirt), dim3(256), 0, c->ctx->stream, (const short *)d_if, (short *)c->d_aux_x,
+                       (const int *)c->d_virt_row, (long long)n);
+    if (int rc = launch_check("post_gather_rows_kernel")) return rc;
+    if (int rc = msdr_chain_process(c->aux, c->d_aux_x, c->d_aux_y, n)) return rc;
+    float kc[4];
+    msdr_syncam_constants(kc);
+    const SyncamConst k{kc[0], kc[1], kc[2], kc[3]};
+    hipLaunchKernelGGL(post_pll_f32_kernel, dim3((c->npost + 63) / 64), dim3(64), 0, c->ctx->stream, (const float *)c->d_aux_y, c->d_post_scratch,
+                       c->d_post_pll_state, (const int *)c->d_post_ch, (const int *)c->d_post_src, (const int *)c->d_post_pll, c->npost, (long long)n, k);
+    if (int rc = launch_check("post_pll_f32_kernel")) return rc;
+    bool any_anr = false;
+    for (int v : c->h_anr) if (v > 0) { any_anr = true; break; }
+    if (any_anr) {
+        hipLaunchKernelGGL(post_anr_f32_kernel, dim3((c->npost + 63) / 64), dim3(64), 0, c->ctx->stream, c->d_post_scratch, c->d_post_anr_state,
+                           (const int *)c->d_post_ch, (const int *)c->d_post_anr, c->npost, (long long)n);
+        if (int rc = launch_check("post_anr_f32_kernel")) return rc;
+    }
+    if (c->post_bq) if (int rc = msdr_biquad_df1_f32_process(c->post_bq, c->d_post_scratch, c->d_post_scratch, (uint32_t)n)) return rc;
+    hipLaunchKernelGGL(post_scatter_rows_kernel, dim3(gx, c->npost), dim3(256), 0, c->ctx->stream, (const float *)c->d_post_scratch, d_audio,
+                       (const int *)c->d_post_ch, (long long)n);
+    return launch_check("post_scatter_rows_kernel");
+}
+
 extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_audio, uint64_t n_samples)
 {
     if (!c) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null chain");
@@ -2701,6 +2846,10 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         if (int rc = msdr_biquad_q15_update(c->nodes[0], (q15_t *)d_audio, (uint32_t)n_samples)) return rc;
     }
 
+    // rows f2 / f3 inside the fp32 chain: PLL / LMS channels are redone behind the main kernel (before the history moves on: a rebuilt
+    // auxiliary chain takes over the history and table position this call started from)
+    if (f32) if (int rc = chain_post_run(c, d_if, (float *)d_audio, n_samples)) return rc;
+
     hipLaunchKernelGGL((history_kernel<int16_t>), dim3(grid_1d((long long)c->channels * c->hist_len)), dim3(256), 0, c->ctx->stream,
                        d_if, (const int16_t *)c->d_hist[c->cur], c->d_hist[c->cur ^ 1], (long long)n_samples, (int)c->hist_len,
                        (int)c->channels);
@@ -2730,6 +2879,13 @@ extern "C" int msdr_chain_reset(msdr_chain *c)
     if (c->pll) if (int rc = msdr_syncam_reset(c->pll)) return rc;
     if (c->anr) if (int rc = msdr_anr_reset(c->anr)) return rc;
     if (c->seq_bq) if (int rc = msdr_biquad_df1_f32_reset(c->seq_bq)) return rc;
+    if (c->aux) { HIP_TRY(hipStreamSynchronize(c->ctx->stream)); chain_post_free(c); c->post_mode_gen = 0; }      // rebuilt from the cleared state
+    if (c->d_post_pll_state) {
+        HIP_TRY(hipMemsetAsync(c->d_post_pll_state, 0, (size_t)c->channels * 4 * sizeof(float), c->ctx->stream));
+        std::vector<float> h((size_t)c->channels * kAnrStateFloats, 0.0f);
+        for (uint32_t ch = 0; ch < c->channels; ch++) { h[(size_t)ch * kAnrStateFloats] = 120.0f; h[(size_t)ch * kAnrStateFloats + 1] = 0.001f; }
+        HIP_TRY(hipMemcpy(c->d_post_anr_state, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     c->phase = 0; c->gen++;
     return 0;
 }
@@ -2805,6 +2961,7 @@ extern "C" int msdr_chain_init_fir(msdr_chain *c)
         }
         HIP_TRY(hipMemcpy(c->d_bq_state, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    if (c->aux) if (int rc = msdr_chain_init_fir(c->aux)) return rc;             // the PLL / LMS channels' filters with it
     const size_t hb = (size_t)c->channels * c->hist_len * sizeof(int16_t);
     HIP_TRY(hipMemsetAsync(c->d_hist[0], 0, hb, c->ctx->stream));
     HIP_TRY(hipMemsetAsync(c->d_hist[1], 0, hb, c->ctx->stream));
@@ -2854,7 +3011,15 @@ extern "C" int msdr_chain_set_anr(msdr_chain *c, const int32_t *anr_on, int32_t 
 {
     if (!c) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null chain");
     if (int rc = bind(c->ctx)) return rc;
-    if (c->arith != MSDR_ARITH_Q15) return fail(MSDR_STATUS_ARGUMENT_ERROR, "the LMS filter works on the int16 audio of a Q15 chain");
+    if (c->arith != MSDR_ARITH_Q15) {
+        // fp32 chain: the float flavour of the filter, between demodulator and cascade (chain_post_run)
+        if (c->seq_bq && !c->h_bq_stages) return fail(MSDR_STATUS_ARGUMENT_ERROR, "internal: cascade coefficients not kept");
+        c->h_anr.assign(c->channels, anr_on ? 0 : (int)anr_on_all);
+        if (anr_on) for (uint32_t ch = 0; ch < c->channels; ch++) c->h_anr[ch] = (int)anr_on[ch];
+        for (int &v : c->h_anr) if (v < 0) v = 0;
+        c->anr_gen++;
+        return 0;
+    }
     if (!c->anr) if (int rc = msdr_anr_create(c->ctx, c->channels, &c->anr)) return rc;
     HIP_TRY(hipStreamSynchronize(c->ctx->stream));
     hipFree(c->d_anr_on); c->d_anr_on = nullptr;

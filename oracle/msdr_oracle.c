@@ -511,8 +511,25 @@ void orc_chain_q15(const orc_chain_q15_cfg *cfg, orc_chain_q15_state *st, const 
  * arm_fir_f32 pair (A6) -> demod (A5 in fp32) -> arm_biquad_cascade_df1_f32 (A8).
  * Sample-sequential; every product and sum is a separately rounded fp32 operation.
  * ====================================================================================== */
-ORC_CLONES void orc_chain_f32(const orc_chain_f32_cfg *cfg, orc_chain_f32_state *st, const int16_t *x,
-                   float *audio, uint64_t n)
+static void orc_chain_f32_core(const orc_chain_f32_cfg *cfg, orc_chain_f32_state *st, orc_chain_f32_post *post, const int16_t *x,
+                               float *audio, uint64_t n);
+void orc_chain_f32(const orc_chain_f32_cfg *cfg, orc_chain_f32_state *st, const int16_t *x, float *audio, uint64_t n)
+{
+    orc_chain_f32_core(cfg, st, NULL, x, audio, n);
+}
+void orc_chain_f32_post_run(const orc_chain_f32_cfg *cfg, orc_chain_f32_state *st, orc_chain_f32_post *post, const int16_t *x,
+                            float *audio, uint64_t n)
+{
+    orc_chain_f32_core(cfg, st, post, x, audio, n);
+}
+void orc_chain_f32_post_init(orc_chain_f32_post *p, int pll, int anr_on)
+{
+    p->pll = pll; p->anr_on = anr_on;
+    orc_syncam_init(&p->pll_state);
+    orc_anr_init(&p->anr_state);
+}
+ORC_CLONES static void orc_chain_f32_core(const orc_chain_f32_cfg *cfg, orc_chain_f32_state *st, orc_chain_f32_post *post, const int16_t *x,
+                               float *audio, uint64_t n)
 {
     const uint32_t N = cfg->num_taps, H = N - 1;
     /* circular-free sliding window: keep 2 copies so a window is always contiguous */
@@ -557,8 +574,12 @@ ORC_CLONES void orc_chain_f32(const orc_chain_f32_cfg *cfg, orc_chain_f32_state 
             switch (cfg->mode) {
             case ORC_LSB: d = ai - aq; break;
             case ORC_USB: d = ai + aq; break;
-            default:      d = sqrtf(ai * ai + aq * aq); break;
+            default:
+                if (post && post->pll && cfg->mode == ORC_SYNCAM) d = orc_syncam_step_f32(&post->pll_state, ai, aq);   /* .ino:631-688 */
+                else d = sqrtf(ai * ai + aq * aq);
+                break;
             }
+            if (post && post->anr_on > 0) d = orc_anr_step_f32(&post->anr_state, post->anr_on, d);                   /* .ino:702-770 */
             for (uint32_t s = 0; s < cfg->num_stages; s++) {
                 const float *c = cfg->bq_coeffs + 5 * s;
                 float *q = bs + 4 * s;
@@ -803,6 +824,36 @@ void orc_syncam_q15(orc_syncam *s, const int16_t *I, const int16_t *Q, int16_t *
     s->fil_out = fil_out; s->omega2 = omega2; s->phzerror = phzerror;
 }
 
+/* the same loop body on float samples (fp32 chain; msdr_oracle.h): out = corr[0], not truncated */
+float orc_syncam_step_f32(orc_syncam *s, float I, float Q)
+{
+    float c[4];
+    orc_syncam_constants(c);
+    const float omega_min = c[0], omega_max = c[1], g1 = c[2], g2 = c[3];
+    float fil_out = s->fil_out, omega2 = s->omega2, phzerror = s->phzerror;
+    const float Sin = (float)sin((double)phzerror);                 /* :660 */
+    const float Cos = (float)cos((double)phzerror);                 /* :661 */
+    const float ai = Cos * I, bi = Sin * I;                         /* :662-663 */
+    const float aq = Cos * Q, bq = Sin * Q;                         /* :664-665 */
+    const float corr0 = +ai + bq;                                   /* :667 */
+    const float corr1 = -bi + aq;                                   /* :668 */
+    const float det = (float)atan2((double)corr1, (double)corr0);   /* :674 */
+    const float del_out = fil_out;                                  /* :677 */
+    omega2 = omega2 + g2 * det;                                     /* :678 */
+    if (omega2 < omega_min) omega2 = omega_min;                     /* :679 */
+    else if (omega2 > omega_max) omega2 = omega_max;                /* :680 */
+    fil_out = g1 * det + omega2;                                    /* :681 */
+    phzerror = phzerror + del_out;                                  /* :682 */
+    while ((double)phzerror >= 2 * ORC_PI_ARDUINO) phzerror = (float)((double)phzerror - 2.0 * ORC_PI_ARDUINO);   /* :685 */
+    while ((double)phzerror < 0.0) phzerror = (float)((double)phzerror + 2.0 * ORC_PI_ARDUINO);                  /* :686 */
+    s->fil_out = fil_out; s->omega2 = omega2; s->phzerror = phzerror;
+    return corr0;                                                   /* :670 without the int16 store */
+}
+void orc_syncam_f32(orc_syncam *s, const float *I, const float *Q, float *out, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++) out[i] = orc_syncam_step_f32(s, I[i], Q[i]);
+}
+
 /* ======================================================================================
  * Row f3: LMS automatic notch / noise reduction, Minimal-SDR.ino:702-770.  See msdr_oracle.h.
  * ====================================================================================== */
@@ -855,6 +906,51 @@ void orc_anr_q15(orc_anr *a, int ANR_on, int16_t *p_dac, uint32_t n)
         ANR_in_idx = (ANR_in_idx + ANR_mask) & ANR_mask;          /* :768 */
     }
     a->lidx = ANR_lidx; a->ngamma = ANR_ngamma; a->in_idx = ANR_in_idx;
+}
+
+/* the same loop body on one float sample (fp32 chain; msdr_oracle.h): int16 units inside, nothing truncated */
+float orc_anr_step_f32(orc_anr *a, int ANR_on, float sample)
+{
+    if (!(ANR_on > 0)) return sample;                             /* :702 */
+    static const int ANR_taps = ORC_ANR_TAPS, ANR_delay = ORC_ANR_DELAY;
+    static const float ANR_two_mu = 0.001, ANR_gamma = 0.1;
+    static const float ANR_lidx_min = 0.0, ANR_lidx_max = 200.0;
+    static const float ANR_den_mult = 6.25e-10, ANR_lincr = 1.0, ANR_ldecr = 3.0;
+    const int ANR_mask = ORC_ANR_DLINE - 1;
+    float *ANR_d = a->d, *ANR_w = a->w;
+    const int ANR_in_idx = a->in_idx;
+    int j, idx;
+    float c0, c1, y, error, sigma, inv_sigp, nel, nev, out;
+    ANR_d[ANR_in_idx] = sample * 32768.0f;                        /* :734, in the reference's sample units */
+    y = 0; sigma = 0;
+    for (j = 0; j < ANR_taps; j++) {                              /* :739-744 */
+        idx = (ANR_in_idx + j + ANR_delay) & ANR_mask;
+        y += ANR_w[j] * ANR_d[idx];
+        sigma += ANR_d[idx] * ANR_d[idx];
+    }
+    inv_sigp = 1.0 / (sigma + 1e-10);                             /* :745 */
+    error = ANR_d[ANR_in_idx] - y;                                /* :746 */
+    out = (ANR_on == 1 ? error : y) * (1.0f / 32768.0f);          /* :749-750 without the int16 store */
+    if ((nel = error * (1.0 - ANR_two_mu * sigma * inv_sigp)) < 0.0) nel = -nel;                                           /* :752 */
+    if ((nev = ANR_d[ANR_in_idx] - (1.0 - ANR_two_mu * a->ngamma) * y - ANR_two_mu * error * sigma * inv_sigp) < 0.0) nev = -nev;   /* :753 */
+    if (nev < nel) {                                              /* :754-757, as written */
+        if ((a->lidx += ANR_lincr) > ANR_lidx_max) a->lidx = ANR_lidx_max;
+        else if ((a->lidx -= ANR_ldecr) < ANR_lidx_min) a->lidx = ANR_lidx_min;
+    }
+    a->ngamma = ANR_gamma * (a->lidx * a->lidx) * (a->lidx * a->lidx) * ANR_den_mult;   /* :758 */
+    c0 = 1.0 - ANR_two_mu * a->ngamma;                            /* :760 */
+    c1 = ANR_two_mu * error * inv_sigp;                           /* :761 */
+    for (j = 0; j < ANR_taps; j++) {                              /* :763-767 */
+        idx = (ANR_in_idx + j + ANR_delay) & ANR_mask;
+        ANR_w[j] = c0 * ANR_w[j] + c1 * ANR_d[idx];
+    }
+    a->in_idx = (ANR_in_idx + ANR_mask) & ANR_mask;               /* :768 */
+    return out;
+}
+void orc_anr_f32(orc_anr *a, int anr_on, float *data, uint32_t n)
+{
+    if (!(anr_on > 0)) return;
+    for (uint32_t i = 0; i < n; i++) data[i] = orc_anr_step_f32(a, anr_on, data[i]);
 }
 
 /* Row f4: output_dac.cpp:139-151 */

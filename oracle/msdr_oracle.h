@@ -228,6 +228,29 @@ void orc_anr_init(orc_anr *a);
 /* anr_on: 1 = notch filter (output = error), 2 = noise reduction (output = y); 0 = off (data untouched, state untouched) */
 void orc_anr_q15(orc_anr *a, int anr_on, int16_t *data, uint32_t n);
 
+/* ======================================================================================
+ * Rows f2 / f3 inside the FP32 chain (an extension: the reference runs both on int16 samples
+ * only).  The same statements as orc_syncam_q15 / orc_anr_q15 on float samples, nothing
+ * truncated.  The PLL is scale-free; the LMS filter has absolute constants (1e-10 under the
+ * normalisation), so it works in the reference's int16 units: sample x 32768 in, / 32768 out
+ * (both exact).  UNPINNED by construction (no reference counterpart); the GPU flavour is checked
+ * against this restatement and both against the q15 functions on integer-valued input.
+ * ====================================================================================== */
+float orc_syncam_step_f32(orc_syncam *s, float I, float Q);                    /* one sample: corr[0] */
+void orc_syncam_f32(orc_syncam *s, const float *I, const float *Q, float *out, uint32_t n);
+float orc_anr_step_f32(orc_anr *a, int anr_on, float sample);                  /* one sample, full scale = 1.0 */
+void orc_anr_f32(orc_anr *a, int anr_on, float *data, uint32_t n);
+typedef struct {
+    int32_t pll;                   /* != 0: ORC_SYNCAM channels demodulate through the PLL (else like AM) */
+    int32_t anr_on;                /* 0 off, 1 notch, 2 noise reduction: between demodulator and biquad cascade (:702-770) */
+    orc_syncam pll_state;
+    orc_anr anr_state;
+} orc_chain_f32_post;
+void orc_chain_f32_post_init(orc_chain_f32_post *p, int pll, int anr_on);
+/* orc_chain_f32 with the PLL branch and the LMS filter in their places; post == NULL: orc_chain_f32 itself */
+void orc_chain_f32_post_run(const orc_chain_f32_cfg *cfg, orc_chain_f32_state *st, orc_chain_f32_post *post, const int16_t *x,
+                            float *audio, uint64_t n);
+
 /* ---- Row f4 (first half): what AudioOutputAnalog::isr hands the 12-bit DAC, src/Audio/output_dac.cpp:139-151:
  * ((sample) + 32768) >> 4 per sample; 2048 (mid-scale) when no block arrived.  UNPINNED (needs the Teensyduino core). */
 void orc_dac_format(const int16_t *src /* NULL = no block */, int16_t *dest, uint32_t n);

@@ -89,6 +89,10 @@ class Frontend(C.Structure):
     _fields_ = [("dc", DcBlock), ("agc", Agc)]
 
 
+class ChainF32Post(C.Structure):
+    _fields_ = [("pll", C.c_int32), ("anr_on", C.c_int32), ("pll_state", Syncam), ("anr_state", Anr)]
+
+
 class Oracle:
     """Thin, numpy-in/numpy-out face of liboracle.so."""
 
@@ -238,6 +242,17 @@ class Oracle:
         self.lib.orc_syncam_q15(C.byref(s), _ptr(i), _ptr(q), _ptr(out), C.c_uint32(i.size))
         return out
 
+    def syncam_f32(self, s, i, q):
+        i, q = np.ascontiguousarray(i, np.float32), np.ascontiguousarray(q, np.float32)
+        out = np.empty(i.size, np.float32)
+        self.lib.orc_syncam_f32(C.byref(s), _ptr(i), _ptr(q), _ptr(out), C.c_uint32(i.size))
+        return out
+
+    def anr_f32(self, a, anr_on, data):
+        d = np.array(data, np.float32)
+        self.lib.orc_anr_f32(C.byref(a), C.c_int(int(anr_on)), _ptr(d), C.c_uint32(d.size))
+        return d
+
     def syncam_constants(self):
         c = np.zeros(4, np.float32)
         self.lib.orc_syncam_constants(_ptr(c))
@@ -356,8 +371,10 @@ class Oracle:
         return cfg, keep
 
     def chain_f32(self, x, mode, coeffs_i, coeffs_q, osc_i, osc_q, bq_coeffs=None, in_scale=1.0 / 32768,
-                  state=None):
-        """One channel; `state` = dict carried between calls (hist_i, hist_q, bq, n0)."""
+                  state=None, pll=False, anr_on=0):
+        """One channel; `state` = dict carried between calls (hist_i, hist_q, bq, n0, post).
+        pll: a SYNCAM channel demodulates through the PLL (.ino:631-688); anr_on 1 / 2: the LMS filter (.ino:702-770) between
+        demodulator and cascade -- the fp32 flavours of rows f2 / f3 (oracle/msdr_oracle.h)."""
         x = np.ascontiguousarray(x, np.int16)
         cfg, keep = self._f32_cfg(mode, coeffs_i, coeffs_q, osc_i, osc_q, bq_coeffs, in_scale)
         h = max(keep[0].size - 1, 1)
@@ -371,7 +388,15 @@ class Oracle:
             st.bq_state[k] = float(v)
         st.n0 = int(state.get("n0", 0))
         out = np.empty(x.size, np.float32)
-        self.lib.orc_chain_f32(C.byref(cfg), C.byref(st), _ptr(x), _ptr(out), C.c_uint64(x.size))
+        if pll or anr_on:
+            post = state.get("post")
+            if post is None:
+                post = ChainF32Post()
+                self.lib.orc_chain_f32_post_init(C.byref(post), C.c_int(1 if pll else 0), C.c_int(int(anr_on)))
+                state["post"] = post
+            self.lib.orc_chain_f32_post_run(C.byref(cfg), C.byref(st), C.byref(post), _ptr(x), _ptr(out), C.c_uint64(x.size))
+        else:
+            self.lib.orc_chain_f32(C.byref(cfg), C.byref(st), _ptr(x), _ptr(out), C.c_uint64(x.size))
         state["bq"] = np.array(list(st.bq_state), np.float32)
         state["n0"] = int(st.n0)
         return out

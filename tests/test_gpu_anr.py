@@ -65,5 +65,5 @@ def test_anr_in_the_q15_chain(ctx, orc):
         audio = orc.anr_q15(orc.anr_new(), anr_on[c], audio)
         want = orc.biquad_teensy_update(orc.biquad_teensy_new([lp]), audio)
         assert np.array_equal(got[c], want), c
-    with pytest.raises(msdr.MsdrError):
-        msdr.Chain(ctx, msdr.ARITH_F32, 1, taps.astype(np.float32), taps.astype(np.float32)).set_anr(None, 1)
+    # (an fp32 chain takes the filter too since round 2 -- its float flavour: tests/test_gpu_chain_post.py)
+    msdr.Chain(ctx, msdr.ARITH_F32, 1, taps.astype(np.float32), taps.astype(np.float32)).set_anr(None, 1)

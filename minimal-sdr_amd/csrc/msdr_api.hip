@@ -1666,8 +1666,9 @@ struct msdr_chain {
     msdr_biquad_df1_f32 *post_bq;
     int npost, nvirt;
     int *d_post_ch, *d_post_src, *d_post_pll, *d_post_anr, *d_virt_row;
+    std::vector<int> h_post_ch;
     float *d_post_pll_state, *d_post_anr_state;      // [channels][4], [channels][kAnrStateFloats]: indexed by CHANNEL, they survive a retune
-    int16_t *d_aux_x; float *d_aux_y, *d_post_scratch; size_t post_cap_n;
+    int16_t *d_aux_x; float *d_aux_y, *d_post_scratch; size_t post_cap_virt, post_cap_post;      // capacities in elements
     msdr_chain_info info;
     // optional per-launch timing of the main kernel
     bool timing;
@@ -1780,7 +1781,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->f32_pll = f32 && (cfg->flags & MSDR_CHAIN_SYNCAM_PLL); c->h_bq_stages = 0; c->anr_gen = 1; c->post_mode_gen = 0; c->post_anr_gen = 0;
     c->aux = nullptr; c->post_bq = nullptr; c->npost = 0; c->nvirt = 0;
     c->d_post_ch = c->d_post_src = c->d_post_pll = c->d_post_anr = c->d_virt_row = nullptr;
-    c->d_post_pll_state = c->d_post_anr_state = nullptr; c->d_aux_x = nullptr; c->d_aux_y = c->d_post_scratch = nullptr; c->post_cap_n = 0;
+    c->d_post_pll_state = c->d_post_anr_state = nullptr; c->d_aux_x = nullptr; c->d_aux_y = c->d_post_scratch = nullptr; c->post_cap_virt = 0; c->post_cap_post = 0;
     if (f32 && cfg->num_biquad_stages) { c->h_bq.assign(cfg->biquad_coeffs, cfg->biquad_coeffs + 5 * cfg->num_biquad_stages); c->h_bq_stages = cfg->num_biquad_stages; }
     if (f32) {
         c->h_coef_i.resize(c->tapsets); c->h_coef_q.resize(c->tapsets);
@@ -2441,7 +2442,15 @@ static bool chain_post_wanted(const msdr_chain *c, uint32_t ch, bool *pll, int *
 static int chain_post_build(msdr_chain *c)
 {
     HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    // the cascade state of channels that stay post channels goes with them (df1 stage state: 16 floats per row)
+    std::vector<float> old_bq;
+    const std::vector<int> old_ch = c->h_post_ch;
+    if (c->post_bq && !old_ch.empty()) {
+        old_bq.resize(old_ch.size() * kBqStateFloats);
+        HIP_TRY(hipMemcpy(old_bq.data(), c->post_bq->d_state, old_bq.size() * sizeof(float), hipMemcpyDeviceToHost));
+    }
     chain_post_free(c);
+    c->h_post_ch.clear();
     c->post_mode_gen = c->mode_gen; c->post_anr_gen = c->anr_gen;
     std::vector<int> post_ch, post_src, post_pll, post_anr, virt_row, virt_mode, virt_ts;
     for (uint32_t ch = 0; ch < c->channels; ch++) {
@@ -2469,8 +2478,17 @@ static int chain_post_build(msdr_chain *c)
     a.flags = c->flags & ~(uint32_t)MSDR_CHAIN_SYNCAM_PLL;
     if (int rc = msdr_chain_create(c->ctx, &a, &c->aux)) return rc;
     c->aux->phase = c->phase;
-    if (c->h_bq_stages)
+    if (c->h_bq_stages) {
         if (int rc = msdr_biquad_df1_f32_create(c->ctx, (uint8_t)c->h_bq_stages, c->h_bq.data(), (uint32_t)post_ch.size(), &c->post_bq)) return rc;
+        if (!old_bq.empty()) {
+            std::vector<float> st(post_ch.size() * kBqStateFloats, 0.0f);
+            for (size_t pn = 0; pn < post_ch.size(); pn++)
+                for (size_t po = 0; po < old_ch.size(); po++)
+                    if (old_ch[po] == post_ch[pn]) { memcpy(&st[pn * kBqStateFloats], &old_bq[po * kBqStateFloats], kBqStateFloats * sizeof(float)); break; }
+            HIP_TRY(hipMemcpy(c->post_bq->d_state, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
+    c->h_post_ch = post_ch;
     if (int rc = upload(c->ctx, post_ch, &c->d_post_ch)) return rc;
     if (int rc = upload(c->ctx, post_src, &c->d_post_src)) return rc;
     if (int rc = upload(c->ctx, post_pll, &c->d_post_pll)) return rc;
@@ -2498,13 +2516,15 @@ static int chain_post_run(msdr_chain *c, const int16_t *d_if, float *d_audio, ui
     if (c->post_mode_gen != c->mode_gen || c->post_anr_gen != c->anr_gen) if (int rc = chain_post_build(c)) return rc;
     if (c->npost == 0) return 0;
     if (n > 0xFFFFFFFFull) return fail(MSDR_STATUS_LENGTH_ERROR, "PLL / LMS channels of an fp32 chain take blocks below 2^32 samples");
-    if (c->post_cap_n < n) {
+    if (c->post_cap_virt < (size_t)c->nvirt * n || c->post_cap_post < (size_t)c->npost * n) {      // (a rebuild may have grown the row counts)
+        HIP_TRY(hipStreamSynchronize(c->ctx->stream));
         hipFree(c->d_aux_x); hipFree(c->d_aux_y); hipFree(c->d_post_scratch);
-        c->d_aux_x = nullptr; c->d_aux_y = nullptr; c->d_post_scratch = nullptr; c->post_cap_n = 0;
-        HIP_TRY(hipMalloc(&c->d_aux_x, (size_t)c->nvirt * n * sizeof(int16_t)));
-        HIP_TRY(hipMalloc(&c->d_aux_y, (size_t)c->nvirt * n * sizeof(float)));
-        HIP_TRY(hipMalloc(&c->d_post_scratch, (size_t)c->npost * n * sizeof(float)));
-        c->post_cap_n = n;
+        c->d_aux_x = nullptr; c->d_aux_y = nullptr; c->d_post_scratch = nullptr; c->post_cap_virt = 0; c->post_cap_post = 0;
+        const size_t cv = std::max(c->post_cap_virt, (size_t)c->nvirt * n), cp = std::max(c->post_cap_post, (size_t)c->npost * n);
+        HIP_TRY(hipMalloc(&c->d_aux_x, cv * sizeof(int16_t)));
+        HIP_TRY(hipMalloc(&c->d_aux_y, cv * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->d_post_scratch, cp * sizeof(float)));
+        c->post_cap_virt = cv; c->post_cap_post = cp;
     }
     const unsigned gx = (unsigned)std::min<uint64_t>(64, (n + 255) / 256);
     hipLaunchKernelGGL(post_gather_rows_kernel, dim3(gx, c->nvirt), dim3(256), 0, c->ctx->stream, (const short *)d_if, (short *)c->d_aux_x,
@@ -2879,7 +2899,7 @@ extern "C" int msdr_chain_reset(msdr_chain *c)
     if (c->pll) if (int rc = msdr_syncam_reset(c->pll)) return rc;
     if (c->anr) if (int rc = msdr_anr_reset(c->anr)) return rc;
     if (c->seq_bq) if (int rc = msdr_biquad_df1_f32_reset(c->seq_bq)) return rc;
-    if (c->aux) { HIP_TRY(hipStreamSynchronize(c->ctx->stream)); chain_post_free(c); c->post_mode_gen = 0; }      // rebuilt from the cleared state
+    if (c->aux) { HIP_TRY(hipStreamSynchronize(c->ctx->stream)); chain_post_free(c); c->h_post_ch.clear(); c->post_mode_gen = 0; }      // rebuilt from the cleared state
     if (c->d_post_pll_state) {
         HIP_TRY(hipMemsetAsync(c->d_post_pll_state, 0, (size_t)c->channels * 4 * sizeof(float), c->ctx->stream));
         std::vector<float> h((size_t)c->channels * kAnrStateFloats, 0.0f);

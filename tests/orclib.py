@@ -218,6 +218,18 @@ class Oracle:
             self.lib.orc_biquad_df1_f32_run(C.byref(S), _ptr(x[o:o + n]), _ptr(y[o:o + n]), C.c_uint32(n))
         return y
 
+    def biquad_df1_zero_state(self, coeffs, x):
+        """arm_biquad_cascade_df1_f32 over x from zero state (one call)"""
+        coeffs = np.ascontiguousarray(coeffs, np.float32).reshape(-1)
+        ns = coeffs.size // 5
+        x = np.ascontiguousarray(x, np.float32)
+        st = np.zeros(4 * max(ns, 1), np.float32)
+        S = BiquadDf1()
+        self.lib.orc_biquad_df1_init_f32(C.byref(S), C.c_uint8(ns), _ptr(coeffs), _ptr(st))
+        y = np.empty_like(x)
+        self.lib.orc_biquad_df1_f32_run(C.byref(S), _ptr(x), _ptr(y), C.c_uint32(x.size))
+        return y
+
     # ---- A9 -----------------------------------------------------------------------------
     # ---- row f3: LMS automatic notch / noise reduction ----
     def anr_new(self):

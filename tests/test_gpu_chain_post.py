@@ -9,13 +9,13 @@ import orclib
 from gpuhelp import ctx, msdr, rel_rms  # noqa: F401
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-5          # as everywhere in the fp32 chain: channels without the LMS filter, PLL channels included
-# LMS channels: the filter's leak control (.ino:754-757) takes a DECISION per sample (nev < nel); an input that differs in the last bit
-# flips some of them, and the oracle itself answers a 1e-7 relative perturbation of its input with 1e-5 .. 5e-5 of the input level at
-# its output, whatever the size of the perturbation (tests/test_oracle_post.py measures it).  No fp32 FIR in front of the filter can be
-# closer than that to another one; the bound for LMS channels is therefore 2e-4, referred to the level in front of the filter (a
-# notch-mode channel outputs what is LEFT of its input).
-TOL_LMS = 2e-4
+TOL = 1e-5          # as everywhere in the fp32 chain
+# LMS channels are checked in two parts.  The filter's leak control (.ino:754-757) takes a DECISION per sample (nev < nel), so its output
+# is discontinuous in its input: the oracle answers a 1e-7 relative perturbation of its own input with 1e-5 .. 5e-5 of the input level
+# (tests/test_oracle_post.py), and a 3e-7 difference in front of the filter has been seen to come out as 4e-3
+# (tests/debug/fuzz_pll_anr_f32.py).  So: (1) the audio IN FRONT of the filter -- a second chain with the filter and the cascade off --
+# against the oracle, 1e-5; (2) the chain's output against the oracle's filter + cascade applied to THAT audio: the filter's arithmetic
+# alone (bit-identical without a cascade), 1e-5 of the level in front of the filter.
 
 
 def _err(got, want, pre=None):
@@ -23,6 +23,10 @@ def _err(got, want, pre=None):
     if pre is not None:
         ref = max(ref, np.sqrt((pre.astype(np.float64) ** 2).sum()))
     return float(np.sqrt(((got.astype(np.float64) - want) ** 2).sum()) / max(ref, 1e-300))
+
+
+def _cascade(orc, v, bq):
+    return orc.biquad_df1_zero_state(bq, v) if bq is not None else v
 
 
 def _lowpass(ntaps):
@@ -83,12 +87,20 @@ def test_chain_f32_syncam_pll_and_lms_filter(ctx, orc, ntaps, stages):
     chain.set_anr(anr)
     splits = [2048, 1000, 129, 64, 10000]
     got = _run(ctx, chain, x, splits)
+    front_chain = msdr.Chain(ctx, msdr.ARITH_F32, len(modes), lp, lp, mixer=msdr.MIXER_FS4, modes=modes, flags=msdr.CHAIN_SYNCAM_PLL)
+    front = _run(ctx, front_chain, x, splits)                      # the audio in front of LMS filter and cascade
     for c in range(len(modes)):
-        st = {}
-        want = np.concatenate([orc.chain_f32(x[c, o:o + m], modes[c], lp, lp, sin4, cos4, bq, state=st, pll=(modes[c] == orclib.SYNCAM), anr_on=anr[c])
-                               for o, m in _segments(n, splits)])
-        pre = orc.chain_f32(x[c], modes[c], lp, lp, sin4, cos4, None, pll=(modes[c] == orclib.SYNCAM)) if anr[c] else None
-        assert _err(got[c], want, pre) < (TOL_LMS if anr[c] else TOL), (c, modes[c], anr[c], _err(got[c], want, pre), rel_rms(got[c], want))
+        pll = modes[c] == orclib.SYNCAM
+        if anr[c]:
+            assert _err(front[c], orc.chain_f32(x[c], modes[c], lp, lp, sin4, cos4, None, pll=pll)) < TOL, (c, "front")
+            want = _cascade(orc, orc.anr_f32(orc.anr_new(), anr[c], front[c]), bq)
+            if bq is None:
+                assert np.array_equal(got[c], want), (c, modes[c], anr[c])          # the filter's arithmetic is the oracle's, bit for bit
+            assert _err(got[c], want, front[c]) < TOL, (c, modes[c], anr[c], _err(got[c], want, front[c]))
+        else:
+            st = {}
+            want = np.concatenate([orc.chain_f32(x[c, o:o + m], modes[c], lp, lp, sin4, cos4, bq, state=st, pll=pll) for o, m in _segments(n, splits)])
+            assert rel_rms(got[c], want) < TOL, (c, modes[c], rel_rms(got[c], want))
     # the PLL really demodulates differently from the envelope (so the test would notice a channel left on the AM branch)
     env = orc.chain_f32(x[0], orclib.AM, lp, lp, sin4, cos4, bq)
     assert rel_rms(got[0], env) > 1e-2
@@ -131,7 +143,7 @@ def test_chain_f32_post_channels_follow_retune_reset_and_switch_off(ctx, orc):
     chain.set_anr([2, 0])
     chain.reset()
     g3 = _run(ctx, chain, x[:, :n], [n])
-    assert _err(g3[0], orc.chain_f32(x[0, :n], orclib.AM, lp, lp, sin4, cos4, None, anr_on=2), orc.chain_f32(x[0, :n], orclib.AM, lp, lp, sin4, cos4, None)) < TOL_LMS
+    assert _err(g3[0], orc.anr_f32(orc.anr_new(), 2, g0[0]), g0[0]) < TOL        # g0[0]: the same channel's audio without the filter (first run)
     chain.set_anr(None, 0)
     chain.set_mode(1, orclib.AM, 0)
     chain.reset()

@@ -868,21 +868,25 @@ def main():
     elif args.workload == "fir":
         args.min_warm_s = 0.2
         out = bench_fir_stage(args, torch, msdr, ctx, dev, rank, world, dist, do_cpu)
-        out["warmup_steps_run"] = args.warmup_steps_run
+        if out is not None:
+            out["warmup_steps_run"] = args.warmup_steps_run
     elif args.workload != "all":
         args.min_warm_s = 0.0 if args.workload == "c3" else 0.2          # the headline config keeps the contract's W steps exactly
         out = bench_chain(args, args.workload, torch, msdr, ctx, dev, rank, world, dist, do_cpu, True)
-        out["warmup_steps_run"] = args.warmup_steps_run
+        if out is not None:
+            out["warmup_steps_run"] = args.warmup_steps_run
     else:
         out = bench_chain(args, "c3", torch, msdr, ctx, dev, rank, world, dist, do_cpu, True)      # the headline, with the CPU baseline
         also = {}
         args.min_warm_s = 0.2                    # sub-records: warm up by time as well as by count (see timed_steps)
         if args.arith == "f32":
             also["fir"] = bench_fir_stage(args, torch, msdr, ctx, dev, rank, world, dist, do_cpu)
-            also["fir"]["warmup_steps_run"] = args.warmup_steps_run
+            if also["fir"] is not None:                  # (records exist on rank 0 only)
+                also["fir"]["warmup_steps_run"] = args.warmup_steps_run
         for name in ("c2", "c4", "c5"):
             also[name] = bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, False, False)   # parity windows, no timed CPU leg
-            also[name]["warmup_steps_run"] = args.warmup_steps_run
+            if also[name] is not None:
+                also[name]["warmup_steps_run"] = args.warmup_steps_run
         args.min_warm_s = 0.0
         if rank == 0:
             for k, rec in also.items():

@@ -1,0 +1,36 @@
+"""bench.py with N > 1 ranks: the control flow the driver's multi-GPU run takes (launcher hop, per-rank shards, max-over-ranks timing,
+records that exist on rank 0 only, the gather section), rehearsed with two ranks on the ONE card of the test box
+(MSDR_BENCH_REHEARSAL=1: gloo collectives on host tensors; a dry run, not a measurement)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_rehearsal_prints_one_complete_line():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MSDR_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                       # rank 0 prints, nobody else
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and len(d["rank_devices"]) == 2 and d["scaling"] == "weak"
+    assert set(d["also"]) == {"fir", "c2", "c4", "c5"}
+    for name, rec in [("c3", d)] + list(d["also"].items()):
+        assert rec["roofline"]["frac"] > 0, name
+        if name != "fir":                                        # (the FIR stage's parity needs the CPU leg, off here)
+            assert rec["parity"] is not None, name
+    assert {"all_gather", "gather_to_root", "overlapped", "c_abi"} <= set(d["gather"])
+    assert "rehearsal" in d

@@ -233,8 +233,13 @@ static int upload(msdr_ctx *ctx, const std::vector<T> &h, T **d)
     *d = nullptr;
     HIP_TRY(hipMalloc((void **)d, std::max<size_t>(h.size() * sizeof(T), 16)));
     if (!h.empty()) {
-        HIP_TRY(hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        // (a failing copy must not leave the buffer behind: callers treat a non-zero return as "nothing was allocated")
+        hipError_t e = hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(*d); *d = nullptr;
+            return fail(MSDR_STATUS_HIP_ERROR, "upload of %zu bytes failed: %s", h.size() * sizeof(T), hipGetErrorString(e));
+        }
     }
     return 0;
 }
@@ -244,7 +249,11 @@ static int dzalloc(msdr_ctx *ctx, size_t count, T **d)
     *d = nullptr;
     size_t bytes = std::max<size_t>(count * sizeof(T), 16);
     HIP_TRY(hipMalloc((void **)d, bytes));
-    HIP_TRY(hipMemsetAsync(*d, 0, bytes, ctx->stream));
+    const hipError_t e = hipMemsetAsync(*d, 0, bytes, ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(*d); *d = nullptr;
+        return fail(MSDR_STATUS_HIP_ERROR, "clearing %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    }
     return 0;
 }
 static int grid_1d(long long total, int block = 256)
@@ -1011,7 +1020,7 @@ extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, cons
     int rc = upload(ctx, tabs, &S->d_tabs);
     if (!rc) rc = dzalloc(ctx, (size_t)channels * kBqStateFloats, &S->d_state);
     if (!rc) rc = dzalloc(ctx, (size_t)channels * kBqStateFloats, &S->d_state_alt);
-    if (rc) { hipFree(S->d_tabs); hipFree(S->d_state); hipFree(S->d_state_alt); delete S; return rc; }
+    if (rc) { hipFree(S->d_tabs); hipFree(S->d_state); hipFree(S->d_state_alt); hipFree(S->d_coeffs); delete S; return rc; }
     *out = S;
     return 0;
 }

@@ -1318,7 +1318,13 @@ extern "C" int msdr_frontend_update(msdr_frontend *fe, const void *d_adc, q15_t 
     if (blockSize % 128u) return fail(MSDR_STATUS_LENGTH_ERROR, "the front end runs in AUDIO_BLOCK_SAMPLES = 128 blocks: blockSize %u is not a multiple", blockSize);
     if (stages & ~MSDR_FE_ALL) return fail(MSDR_STATUS_ARGUMENT_ERROR, "unknown stage bits");
     if (stages == MSDR_FE_ALL && (fe->channels & 63u) == 0 && (reinterpret_cast<uintptr_t>(d_adc) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 &&
-        !getenv("MSDR_NO_FRONTEND_PIPE")) {      // DC block on one wave, gain + AGC on the next: a two-wave slab pipeline
+        !getenv("MSDR_NO_FRONTEND_PIPE")) {
+        if (!getenv("MSDR_NO_FRONTEND_PIPE4")) {     // the recursion alone on one wave, everything element-wise on three more (msdr_frontend.hiph)
+            hipLaunchKernelGGL(frontend_pipe4_kernel, dim3(fe->channels / 64), dim3(kFe4Threads), kFe4LdsBytes, fe->ctx->stream, (const unsigned short *)d_adc,
+                               (short *)d_out, fe->d_state, (int)fe->channels, (long long)blockSize);
+            return launch_check("frontend_pipe4_kernel");
+        }
+        // DC block on one wave, gain + AGC on the next: a two-wave slab pipeline
         hipLaunchKernelGGL(frontend_pipe_kernel, dim3(fe->channels / 64), dim3(128), 0, fe->ctx->stream, (const unsigned short *)d_adc,
                            (short *)d_out, fe->d_state, (int)fe->channels, (long long)blockSize);
         return launch_check("frontend_pipe_kernel");

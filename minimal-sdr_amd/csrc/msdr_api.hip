@@ -1111,6 +1111,7 @@ struct msdr_biquad_q15 {
     msdr_ctx *ctx;
     uint32_t channels;
     int *d_defs;      // [channels][32]
+    int max_stage;    // highest stage index given to setCoefficients so far (-1: none): stages above 0 chain through the records' flag bits
 };
 
 // filter_biquad.cpp:84-100 applied to every channel's record
@@ -1134,7 +1135,7 @@ extern "C" int msdr_biquad_q15_create(msdr_ctx *ctx, uint32_t channels, msdr_biq
     if (channels == 0) return fail(MSDR_STATUS_ARGUMENT_ERROR, "channels == 0");
     msdr_biquad_q15 *S = new (std::nothrow) msdr_biquad_q15();
     if (!S) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
-    S->ctx = ctx; S->channels = channels; S->d_defs = nullptr;
+    S->ctx = ctx; S->channels = channels; S->d_defs = nullptr; S->max_stage = -1;
     if (int rc = dzalloc(ctx, (size_t)channels * 32, &S->d_defs)) { delete S; return rc; }   // h:36-39: passes nothing
     *out = S;
     return 0;
@@ -1144,6 +1145,7 @@ extern "C" int msdr_biquad_q15_set_coefficients(msdr_biquad_q15 *S, uint32_t sta
     if (!S || !coef) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
     if (stage >= 4) return 0;                                   // filter_biquad.cpp:86: silently ignored
     if (int rc = bind(S->ctx)) return rc;
+    S->max_stage = std::max(S->max_stage, (int)stage);
     hipLaunchKernelGGL(tbq_set_coef_kernel, dim3(grid_1d(S->channels)), dim3(256), 0, S->ctx->stream, S->d_defs, (int)S->channels,
                        (int)stage, coef[0], coef[1], coef[2], coef[3], coef[4]);
     return launch_check("tbq_set_coef_kernel");
@@ -1624,7 +1626,7 @@ struct msdr_chain {
     float *d_fft_h, *d_fft_tw;
     void *d_bq_fft;
     // matrix-core path (msdr_chain_mfma.hiph): any short-period oscillator, any mode
-    bool no_biquad_pipe;                                  // MSDR_NO_BIQUAD_PIPE, read once at creation (A/B switch for the two-wave node pipeline)
+    bool no_biquad_pipe, no_biquad_pipe4;                 // MSDR_NO_BIQUAD_PIPE / MSDR_NO_BIQUAD_PIPE4, read once at creation (A/B switches for the node pipelines)
     bool mf_ok;
     int mf_halo, mf_bsteps, mf_stride;
     char *d_mf_tab;
@@ -1785,7 +1787,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->pole_radius = c->nstages ? max_pole_radius(cfg->biquad_coeffs, (int)c->nstages) : 0.0;
     c->cur = 0; c->phase = 0; c->timing = false; c->timed_ms = 0; c->timed_launches = 0;
     c->gen = 1; c->dh_cache.resize(c->channels); c->dh_gen.assign(c->channels, 0);
-    c->no_biquad_pipe = getenv("MSDR_NO_BIQUAD_PIPE") != nullptr;
+    c->no_biquad_pipe = getenv("MSDR_NO_BIQUAD_PIPE") != nullptr; c->no_biquad_pipe4 = getenv("MSDR_NO_BIQUAD_PIPE4") != nullptr;
     c->flags = cfg->flags; c->mfw_nw = 0; c->mfw_waves_per_cu = 0; c->d_bq_state_alt = nullptr; c->d_mw_iir = nullptr; c->d_units = nullptr; c->units_cap = 0;
     c->mode_gen = 1; c->units_mode_gen = 0; c->units_nseg = 0; c->units_wgs = 0; c->units_wgs_ssb = 0; c->mfw_ssb_fold = false; c->mfw_am_fold = false; c->units_tiles = -1;
     c->part_nseg[0] = c->part_nseg[1] = 1; c->part_seg_len[0] = c->part_seg_len[1] = 0;
@@ -2870,7 +2872,12 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         if (int rc = msdr_anr_q15(c->anr, c->d_anr_on, c->anr_all, (q15_t *)d_audio, (uint32_t)n_samples)) return rc;
 
     if (c->nnodes == 2) {      // biquad1_dac -> biquad2_dac in one pass over the audio
-        if ((c->channels & 63u) == 0 && (n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 && !c->no_biquad_pipe)
+        const bool slabs = (c->channels & 63u) == 0 && (n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 && !c->no_biquad_pipe;
+        if (slabs && c->nodes[0]->max_stage == 0 && c->nodes[1]->max_stage == 0 && !c->no_biquad_pipe4)
+            // one stage per node (the reference's configuration): the recursions alone on two waves, the input products element-wise on fourteen more
+            hipLaunchKernelGGL(biquad_teensy_pipe4_kernel, dim3(c->channels / 64), dim3(kTq4Threads), kTq4LdsBytes, c->ctx->stream, (short *)d_audio,
+                               c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);
+        else if (slabs)
             hipLaunchKernelGGL(biquad_teensy_pipe_kernel, dim3(c->channels / 64), dim3(128), 0, c->ctx->stream, (short *)d_audio,
                                c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);     // node per wave, slab pipeline
         else

@@ -1157,6 +1157,12 @@ extern "C" int msdr_biquad_q15_update(msdr_biquad_q15 *S, q15_t *d_data, uint32_
     if (blockSize == 0) return 0;
     if (!d_data) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
     if (blockSize & 1u) return fail(MSDR_STATUS_LENGTH_ERROR, "AudioFilterBiquad processes sample pairs: blockSize must be even");
+    if (S->max_stage == 0 && (S->channels & 63u) == 0 && (blockSize & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_data) & 15) == 0 && !getenv("MSDR_NO_BIQUAD_PIPE4")) {
+        // one stage, slab-shaped batch: the recursion alone on one wave, the input products element-wise on six more (msdr_kernels.hiph)
+        hipLaunchKernelGGL(biquad_teensy_pipe4_kernel<1>, dim3(S->channels / 64), dim3(kTq4Threads), kTq4LdsBytes, S->ctx->stream, (short *)d_data,
+                           S->d_defs, (int *)nullptr, (int)S->channels, (long long)blockSize);
+        return launch_check("biquad_teensy_pipe4_kernel<1>");
+    }
     hipLaunchKernelGGL((biquad_teensy_kernel<1>), dim3((S->channels + 63) / 64), dim3(64), 0, S->ctx->stream, d_data, S->d_defs,
                        (int *)nullptr, (int)S->channels, (long long)blockSize);
     return launch_check("biquad_teensy_kernel");
@@ -2875,7 +2881,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         const bool slabs = (c->channels & 63u) == 0 && (n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 && !c->no_biquad_pipe;
         if (slabs && c->nodes[0]->max_stage == 0 && c->nodes[1]->max_stage == 0 && !c->no_biquad_pipe4)
             // one stage per node (the reference's configuration): the recursions alone on two waves, the input products element-wise on fourteen more
-            hipLaunchKernelGGL(biquad_teensy_pipe4_kernel, dim3(c->channels / 64), dim3(kTq4Threads), kTq4LdsBytes, c->ctx->stream, (short *)d_audio,
+            hipLaunchKernelGGL(biquad_teensy_pipe4_kernel<2>, dim3(c->channels / 64), dim3(kTq4Threads), kTq4LdsBytes, c->ctx->stream, (short *)d_audio,
                                c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);
         else if (slabs)
             hipLaunchKernelGGL(biquad_teensy_pipe_kernel, dim3(c->channels / 64), dim3(128), 0, c->ctx->stream, (short *)d_audio,

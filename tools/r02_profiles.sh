@@ -19,7 +19,7 @@ echo "fir counters done"
 {
   for w in fir c3 c2 c4 c5; do
     echo "---- $w"
-    STEPS=$([ $w = c4 ] && echo 30000 || echo 4000) bash tools/smi_probe.sh $w -- --workload $w 2>&1 | grep -E "sclk|ms " | sed 's/GPU\[0\]\s*: //g; s/=\+ Power Consumption =\+//'
+    STEPS=$(case $w in c4) echo 30000;; c5) echo 12000;; *) echo 4000;; esac) bash tools/smi_probe.sh $w -- --workload $w 2>&1 | grep -E "sclk|ms " | sed 's/GPU\[0\]\s*: //g; s/=\+ Power Consumption =\+//'
   done
 } > gpurun_out/r02/power_clock_samples.txt 2>&1
 echo "power samples done"

@@ -241,6 +241,38 @@ def test_biquad_q15_bit_exact(ctx, orc, n_stage):
     assert e.value.status == msdr.STATUS_LENGTH_ERROR
 
 
+@pytest.mark.parametrize("kind", ["lowpass", "notch"])
+def test_biquad_q15_one_stage_node_on_the_slab_pipeline(ctx, orc, kind):
+    """A one-stage node over a slab-shaped batch (channels a multiple of 64, blocks a multiple of 128: the reference's cadence) runs on
+    biquad_teensy_pipe4_kernel<1> -- the recursion alone on one wave, the input products element-wise beside it.  Bit-exact incl. the
+    state record, saturation, several calls; a second stage sends the node back to the per-lane kernel."""
+    rng = np.random.default_rng(60 + len(kind))
+    corr = orclib.AUDIO_SAMPLE_RATE_EXACT / 24000.0
+    coef = orc.biquad_design(orclib.BQ_LOWPASS, np.float32(5400 * corr), 0.54) if kind == "lowpass" else orc.biquad_design(orclib.BQ_NOTCH, np.float32(3000 * corr), 15.0)
+    ch = 128
+    node = msdr.BiquadQ15(ctx, ch)
+    node.set_coefficients(0, coef)
+    refs = [orc.biquad_teensy_new([coef]) for _ in range(ch)]
+    for blk, nb in enumerate([1, 3, 2, 5]):
+        n = nb * B
+        x = _rand16(rng, (ch, n), 32767 if blk == 2 else 6000)
+        if blk == 2:
+            x[:, : n // 2] = 32767
+        d = ctx.to_device(x)
+        node.update(d, n)
+        got = d.download()
+        for c in (0, 1, 63, 64, 127):
+            assert np.array_equal(got[c], orc.biquad_teensy_update(refs[c], x[c])), (blk, c)
+    for c in (0, 63, 64, 127):
+        assert list(node.definition(c)) == list(refs[c].definition), c
+    node.set_coefficients(1, coef)                                 # two stages now: per-lane kernel, same stream
+    orc.lib.orc_biquad_teensy_set_coefficients(orclib.C.byref(refs[1]), 1, coef.ctypes.data_as(orclib._p))      # (channel 1's model has followed every block)
+    x = _rand16(rng, (ch, 2 * B), 6000)
+    d = ctx.to_device(x)
+    node.update(d, 2 * B)
+    assert np.array_equal(d.download()[1], orc.biquad_teensy_update(refs[1], x[1]))
+
+
 @pytest.mark.parametrize("scale,rng_hint", [(8000.0, None), (32767.0, None), (1.0, None), (1e-3, None), (3.0e6, None), (1e-20, None), (1e30, None),
                                             (1.0, 1.0), (3.0e6, 4.0e6)])
 def test_fir_f32_matrix_core_input_ranges(ctx, orc, scale, rng_hint):

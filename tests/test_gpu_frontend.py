@@ -35,7 +35,7 @@ def _check_state(fe, f_orc, c):
     assert list(buf) == list(f_orc.agc.agc_buffer)
 
 
-@pytest.mark.parametrize("ch,call_blocks", [(1, 40), (64, 7), (70, 1), (130, 13), (128, 3), (192, 80)])   # whole 64-channel groups: the two-wave pipeline
+@pytest.mark.parametrize("ch,call_blocks", [(1, 40), (64, 7), (70, 1), (130, 13), (128, 3), (192, 80), (64, 1), (64, 2)])   # whole 64-channel groups: the slab pipelines
 @pytest.mark.parametrize("level", [400, 9000, 31000])
 def test_frontend_matches_oracle(ctx, orc, ch, call_blocks, level):
     """Whole front end over many calls (state carried in HBM), channel counts around the 64-lane workgroup, levels that
@@ -60,6 +60,22 @@ def test_frontend_matches_oracle(ctx, orc, ch, call_blocks, level):
         assert np.array_equal(got[c], want), c
         if c in (0, ch - 1):
             _check_state(fe, f, c)
+
+
+def test_frontend_in_place_on_the_slab_pipeline(ctx, orc):
+    """in == out (the ADC words are overwritten by the conditioned samples, as the reference's node does with its block): the slab
+    pipeline loads slab t + 2 -- and the sample in front of it -- before slab t - 1 is stored"""
+    rng = np.random.default_rng(5)
+    ch, nblk = 64, 11
+    x = _adc(rng, ch, nblk, 9000)
+    fe = msdr.Frontend(ctx, ch)
+    fe.prime(x[:, 0])
+    d = ctx.to_device(x.view(np.int16))
+    fe.update(d, d, nblk * B)
+    got = d.download()
+    for c in (0, 17, 63):
+        f = orc.frontend_new(first_conversion=int(x[c, 0]))
+        assert np.array_equal(got[c], orc.frontend_run(f, x[c])), c
 
 
 def test_frontend_stage_selection_and_controls(ctx, orc):

@@ -734,6 +734,25 @@ def test_chain_q15_two_biquad_nodes_pipeline(ctx, orc, golden, ch):
             assert np.array_equal(got[c], want), (ch, c)
 
 
+@pytest.mark.parametrize("block", [B, 2 * B, 3 * B, None])
+def test_chain_q15_one_stage_nodes_on_the_slab_pipeline(ctx, orc, golden, block):
+    """The reference's configuration -- one stage per node (low-pass .ino:391-393, Q = 15 notch .ino:356) -- on whole 64-channel groups:
+    biquad_teensy_pipe4_kernel<2> (the two recursions alone on two waves).  Calls of one, two and three slabs (the pipeline's start-up
+    and drain paths) and one long call; full-scale square wave; state carried from call to call."""
+    rng = np.random.default_rng(7)
+    ch, n = 128, 12 * B
+    x = rng.integers(-32768, 32768, (ch, n)).astype(np.int16)
+    x[1] = np.where((np.arange(n) // 40) % 2, 32767, -32768)
+    taps = golden["fir/taps_am102"]
+    lp = orc.biquad_design(orclib.BQ_LOWPASS, np.float32(5400 * CORR), 0.54)
+    nt = orc.biquad_design(orclib.BQ_NOTCH, np.float32(3000 * CORR), 15.0)
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, taps, taps, mode=orclib.AM, biquad_nodes=[[lp], [nt]])
+    got = run_chain(ctx, chain, x, np.int16, block)
+    for c in (0, 1, 63, 64, 127):
+        want = orc.chain_q15(x[c], orclib.AM, taps, taps, biquads=[orc.biquad_teensy_new([lp]), orc.biquad_teensy_new([nt])])
+        assert np.array_equal(got[c], want), (block, c)
+
+
 @pytest.mark.parametrize("variant", ["fs4", "swapped", "minus32768", "gaps", "period8"])
 def test_chain_q15_nco_tables_on_matrix_cores(ctx, orc, golden, variant):
     """AudioEffectFreqConv tables of period 4 with alternating zeros (the node driven at fs/4) run on the matrix-core kernel:

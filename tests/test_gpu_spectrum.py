@@ -44,6 +44,47 @@ def test_rfft128_matches_oracle(ctx, orc, nfft, stride):
         assert np.array_equal(col[f], orc.spectrum_columns(want)), f
 
 
+def test_rfft128_saturating_and_halving_paths(ctx, orc):
+    """Inputs that drive the packed saturating adds (__QADD16 / __QASX ...), the halving adds at both ends of the 16-bit range and
+    the wrapping twiddle sums: constants and square waves at full scale, impulses, single bins at full scale."""
+    rows = []
+    for v in (-32768, 32767, -1, 1, 0):
+        rows.append(np.full(128, v))
+    k = np.arange(128)
+    for period in (2, 4, 8, 16, 32, 64, 128):
+        sq = np.where((k // (period // 2)) % 2 == 0, 32767, -32768)
+        rows += [sq, -1 - sq, np.roll(sq, 1), np.where(k % 2 == 0, sq, 0), np.where(k % 2 == 1, sq, 0)]
+    for pos in (0, 1, 2, 63, 64, 126, 127):
+        for v in (-32768, 32767):
+            imp = np.zeros(128)
+            imp[pos] = v
+            rows.append(imp)
+    for b in (1, 3, 16, 31, 32, 33, 63):
+        for ph in (0.0, 0.7):
+            rows.append(np.clip(np.round(40000 * np.cos(2 * np.pi * b * k / 128 + ph)), -32768, 32767))
+    x = np.array(rows).astype(np.int16)
+    out, col = _run(ctx, x)
+    for f in range(x.shape[0]):
+        want, _ = orc.rfft128_q15(x[f])
+        assert np.array_equal(out[f], want), f
+        assert np.array_equal(col[f], orc.spectrum_columns(want)), f
+
+
+def test_rfft128_more_batches_than_workgroups(ctx, orc):
+    """The launch is capped at 8192 workgroups of 16 transforms: beyond 131 072 transforms a workgroup walks several batches, the next
+    batch's samples already on their way while one is transformed.  Checked: the head, the seams between walks and the ragged tail."""
+    nfft = 2 * 8192 * 16 + 16 * 5 + 3
+    rng = np.random.default_rng(77)
+    x = rng.integers(-32768, 32768, (nfft, 128)).astype(np.int16)
+    out, col = _run(ctx, x)
+    picks = np.unique(np.concatenate([np.arange(0, 40), np.arange(131072 - 20, 131072 + 40), np.arange(262144 - 20, nfft),
+                                      rng.integers(0, nfft, 300)]))
+    for f in picks:
+        want, _ = orc.rfft128_q15(x[f])
+        assert np.array_equal(out[f], want), f
+        assert np.array_equal(col[f], orc.spectrum_columns(want)), f
+
+
 def test_rfft128_outputs_optional_and_argument_checks(ctx):
     x = np.arange(256, dtype=np.int16).reshape(2, 128)
     d = ctx.to_device(x)

@@ -1,6 +1,6 @@
 """Randomised differential test of the matrix-core kernels against the oracle (run from the repository root on a GPU box):
     gpurun -- python tests/debug/fuzz_kernels.py [seconds] [seed]
-Q15 chain (random tap counts, tap sets, modes, mixers, call lengths, biquad nodes), arm_fir_fast_q15 stage, arm_fir_f32 stage."""
+Q15 chain (random tap counts, tap sets, modes, mixers, call lengths, biquad nodes), arm_fir_fast_q15 stage, arm_fir_f32 stage, spectrum FFT."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -56,7 +56,7 @@ def splits(n):
 
 
 while time.time() < t_end:
-    which = rng.integers(0, 5)
+    which = rng.integers(0, 6)
     cases += 1
     if which == 0:      # Q15 chain
         ntaps = int(rng.integers(1, 257)) * 2
@@ -256,6 +256,34 @@ while time.time() < t_end:
                 break
             o += m
         chain.close()
+    elif which == 5:    # spectrum FFT (arm_rfft_q15, 128 points) + column heights
+        nfft = int(rng.choice([1, 5, 16, 33, 200]))
+        stride = 128 + 8 * int(rng.integers(0, 3))
+        kind = int(rng.integers(0, 4))
+        k_ = np.arange(128)
+        if kind == 0:
+            xs = rng.integers(-32768, 32768, (nfft, 128))
+        elif kind == 1:
+            xs = rng.integers(-int(rng.choice([3, 300, 9000])), int(rng.choice([3, 300, 9000])) + 1, (nfft, 128))
+        elif kind == 2:     # few strong lines: saturating adds
+            xs = np.zeros((nfft, 128))
+            for _ in range(int(rng.integers(1, 4))):
+                xs += rng.uniform(8000, 45000) * np.cos(2 * np.pi * rng.integers(0, 64, (nfft, 1)) * k_ / 128 + rng.uniform(0, 6.3, (nfft, 1)))
+            xs = np.clip(np.round(xs), -32768, 32767)
+        else:               # two-level signals
+            xs = np.where(rng.integers(0, 2, (nfft, 128)) == 1, 32767, -32768) * rng.integers(0, 2, (nfft, 128))
+        xs = xs.astype(np.int16)
+        buf = np.zeros((nfft, stride), np.int16)
+        buf[:, :128] = xs
+        o_, c_ = ctx.array((nfft, 256), np.int16), ctx.array((nfft, 128), np.uint8)
+        msdr.rfft128_q15(ctx, ctx.to_device(buf), stride, nfft, o_, c_)
+        go, gc = o_.download(), c_.download()
+        for f in rng.choice(nfft, min(nfft, 6), replace=False):
+            want, _ = orc.rfft128_q15(xs[f])
+            if not (np.array_equal(go[f], want) and np.array_equal(gc[f, :127], orc.spectrum_columns(want)) and gc[f, 127] == 0):
+                bad += 1
+                print("MISMATCH spectrum", dict(seed=seed, case=cases, nfft=nfft, stride=stride, kind=kind, f=int(f)))
+                break
     else:               # arm_fir_f32 stage
         ntaps = int(rng.integers(1, 513))
         ch, n = int(rng.choice([1, 5, 70])), int(rng.integers(1, 80)) * B

@@ -261,10 +261,29 @@ def bench_frontend(args, torch, msdr, ctx, dev, rank, world, dist):
            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "q15 (uint16 in, int16 out, int32/int64 recurrences)", "data": "synthetic",
            "config": {"workload": "fe: %d channels x %d raw conversions, DC block + gain + AGC per 128-sample block" % (ch, n),
-                      "channels_per_gpu": ch, "samples_per_channel_per_step": n, "kernel": "frontend_kernel"},
+                      "channels_per_gpu": ch, "samples_per_channel_per_step": n, "kernel": "frontend_pipe4_kernel"},
            "roofline": {"bound": "hbm", "achieved": round(4.0 * ch * n / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(4.0 * ch * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                         "note": "one lane per channel: serial integer recurrences, latency-bound by construction"}}
+    if not (args.channels or args.samples):
+        # The same number of conversions as 4x the channels: a workgroup (64 channels) walks its stream alone, so 4096 channels keep 64 of the
+        # 256 CUs busy and the step time is the per-channel latency (2^18 dependent recursion steps); 16 384 channels fill the chip.
+        chw, nw = 4 * ch, n // 4
+        xw, yw = x.view(-1)[:chw * nw].view(chw, nw), y.view(-1)[:chw * nw].view(chw, nw)     # (the values do not matter for the time)
+        few = msdr.Frontend(ctx, chw)
+        few.prime(np.uint16(32768))
+        for _ in range(3):
+            few.update(xw.data_ptr(), yw.data_ptr(), nw)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            few.update(xw.data_ptr(), yw.data_ptr(), nw)
+        torch.cuda.synchronize(dev)
+        msw = (time.perf_counter() - t1) / args.steps * 1e3
+        few.close()
+        out["wide"] = {"workload": "fe: %d channels x %d raw conversions (the same amount of data, 4x the channels)" % (chw, nw),
+                       "ms_per_step": round(msw, 4), "value": round(chw * nw / (msw * 1e-3) / 1e6, 1),
+                       "roofline_frac": round(4.0 * chw * nw / (msw * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orclib

@@ -12,6 +12,8 @@ bash tools/profile.sh c3 --workload c3 --no-parity > gpurun_out/r02/c3_rocprof_s
 echo "c3 profile done"
 bash tools/profile.sh c2 --workload c2 --no-parity > gpurun_out/r02/c2_rocprof_summary.txt 2>&1
 echo "c2 profile done"
+bash tools/profile.sh spec --workload spec > gpurun_out/r02/spec_rocprof_summary.txt 2>&1
+echo "spec profile done"
 bash tools/pmc.sh c3 --workload c3 --no-parity > gpurun_out/r02/c3_sq_counters.txt 2>&1
 echo "c3 counters done"
 bash tools/pmc.sh fir --workload fir --no-parity > gpurun_out/r02/fir_f32_sq_counters.txt 2>&1

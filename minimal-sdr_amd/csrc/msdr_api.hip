@@ -1263,6 +1263,7 @@ struct msdr_frontend {
     msdr_ctx *ctx;
     uint32_t channels;
     int *d_state;          // [channels][kFeStateInts]
+    int pipe_ch;           // channels per workgroup of frontend_pipe4_kernel (64 / 32 / 16), 0: the two-wave pipeline, -1: no pipeline (read at create time)
 };
 
 static int fe_edit(msdr_frontend *fe, const std::function<void(uint32_t, int *)> &f)
@@ -1286,6 +1287,11 @@ extern "C" int msdr_frontend_create(msdr_ctx *ctx, uint32_t channels, msdr_front
     msdr_frontend *fe = new (std::nothrow) msdr_frontend();
     if (!fe) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
     fe->ctx = ctx; fe->channels = channels; fe->d_state = nullptr;
+    // One workgroup walks its channels' stream alone and its step time is the recursion's latency whether 64, 32 or 16 lanes of the recursion
+    // wave carry a channel -- only the element-wise work beside it grows with the channel count.  So: as few channels per workgroup as still
+    // give every CU one (MI355X: 256 CUs); from 16 384 channels on the CUs are full and 64 per workgroup issue the fewest instructions.
+    fe->pipe_ch = getenv("MSDR_NO_FRONTEND_PIPE") ? -1 : getenv("MSDR_NO_FRONTEND_PIPE4") ? 0 : channels >= 16384 ? 64 : channels >= 8192 ? 32 : 16;
+    if (const char *e = getenv("MSDR_FRONTEND_PIPE_CH")) { const int v = atoi(e); if (v == 64 || v == 32 || v == 16) fe->pipe_ch = v; }
     std::vector<int> h((size_t)channels * kFeStateInts, 0);
     const float agc_start = 0.25f;                       // Minimal-SDR.ino:94
     int bits; memcpy(&bits, &agc_start, sizeof bits);
@@ -1325,17 +1331,21 @@ extern "C" int msdr_frontend_update(msdr_frontend *fe, const void *d_adc, q15_t 
     if (!d_adc || !d_out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
     if (blockSize % 128u) return fail(MSDR_STATUS_LENGTH_ERROR, "the front end runs in AUDIO_BLOCK_SAMPLES = 128 blocks: blockSize %u is not a multiple", blockSize);
     if (stages & ~MSDR_FE_ALL) return fail(MSDR_STATUS_ARGUMENT_ERROR, "unknown stage bits");
-    if (stages == MSDR_FE_ALL && (fe->channels & 63u) == 0 && (reinterpret_cast<uintptr_t>(d_adc) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 &&
-        !getenv("MSDR_NO_FRONTEND_PIPE")) {
-        if (!getenv("MSDR_NO_FRONTEND_PIPE4")) {     // the recursion alone on one wave, everything element-wise on three more (msdr_frontend.hiph)
-            hipLaunchKernelGGL(frontend_pipe4_kernel, dim3(fe->channels / 64), dim3(kFe4Threads), kFe4LdsBytes, fe->ctx->stream, (const unsigned short *)d_adc,
-                               (short *)d_out, fe->d_state, (int)fe->channels, (long long)blockSize);
-            return launch_check("frontend_pipe4_kernel");
+    if (stages == MSDR_FE_ALL && fe->pipe_ch >= 0 && (reinterpret_cast<uintptr_t>(d_adc) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) {
+        // the recursion alone on one wave, everything element-wise on the others (msdr_frontend.hiph)
+#define MSDR_FE4_LAUNCH(CH_)                                                                                                                              \
+        if (fe->pipe_ch == CH_ && fe->channels % CH_ == 0) {                                                                                              \
+            hipLaunchKernelGGL(frontend_pipe4_kernel<CH_>, dim3(fe->channels / CH_), dim3(fe4_threads(CH_)), fe4_lds_bytes(CH_), fe->ctx->stream,         \
+                               (const unsigned short *)d_adc, (short *)d_out, fe->d_state, (int)fe->channels, (long long)blockSize);                      \
+            return launch_check("frontend_pipe4_kernel");                                                                                                 \
         }
-        // DC block on one wave, gain + AGC on the next: a two-wave slab pipeline
-        hipLaunchKernelGGL(frontend_pipe_kernel, dim3(fe->channels / 64), dim3(128), 0, fe->ctx->stream, (const unsigned short *)d_adc,
-                           (short *)d_out, fe->d_state, (int)fe->channels, (long long)blockSize);
-        return launch_check("frontend_pipe_kernel");
+        MSDR_FE4_LAUNCH(64) MSDR_FE4_LAUNCH(32) MSDR_FE4_LAUNCH(16)
+#undef MSDR_FE4_LAUNCH
+        if ((fe->channels & 63u) == 0) {   // DC block on one wave, gain + AGC on the next: a two-wave slab pipeline
+            hipLaunchKernelGGL(frontend_pipe_kernel, dim3(fe->channels / 64), dim3(128), 0, fe->ctx->stream, (const unsigned short *)d_adc,
+                               (short *)d_out, fe->d_state, (int)fe->channels, (long long)blockSize);
+            return launch_check("frontend_pipe_kernel");
+        }
     }
     hipLaunchKernelGGL(frontend_kernel, dim3((fe->channels + 63) / 64), dim3(64), 0, fe->ctx->stream, (const unsigned short *)d_adc,
                        (short *)d_out, fe->d_state, (int)fe->channels, (long long)blockSize, (int)stages);

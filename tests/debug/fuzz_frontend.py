@@ -18,7 +18,11 @@ case = bad = 0
 while time.time() < t_end:
     case += 1
     rng = np.random.default_rng([seed, case])
-    ch = int(rng.choice([1, 5, 64, 65, 128, 192, 200, 256]))
+    ch = int(rng.choice([1, 5, 16, 48, 64, 65, 128, 192, 200, 256]))
+    os.environ.pop("MSDR_FRONTEND_PIPE_CH", None)
+    per_group = int(rng.choice([0, 16, 32, 64]))          # frontend_pipe4_kernel<CH>: the host's own choice, or forced (read at create time)
+    if per_group:
+        os.environ["MSDR_FRONTEND_PIPE_CH"] = str(per_group)
     nblk = int(rng.integers(1, 60))
     n = nblk * B
     kind = int(rng.integers(0, 4))

@@ -62,6 +62,33 @@ def test_frontend_matches_oracle(ctx, orc, ch, call_blocks, level):
             _check_state(fe, f, c)
 
 
+@pytest.mark.parametrize("per_group", [16, 32, 64])
+@pytest.mark.parametrize("call_blocks", [1, 2, 9])
+def test_frontend_slab_pipeline_channels_per_workgroup(ctx, orc, per_group, call_blocks, monkeypatch):
+    """frontend_pipe4_kernel<CH>: the host picks 16, 32 or 64 channels per workgroup from the batch size (read at create time);
+    every instantiation against the oracle, state records included, over calls of one, two and nine blocks."""
+    monkeypatch.setenv("MSDR_FRONTEND_PIPE_CH", str(per_group))
+    ch, nblk = 128, 27
+    rng = np.random.default_rng(per_group * 10 + call_blocks)
+    x = _adc(rng, ch, nblk, 14000)
+    x[5, 300:340] = 65535
+    x[5, 340:420] = 0
+    fe = msdr.Frontend(ctx, ch)
+    fe.prime(x[:, 0])
+    got = np.empty((ch, nblk * B), np.int16)
+    for b0 in range(0, nblk, call_blocks):
+        m = min(call_blocks, nblk - b0) * B
+        dx, dy = ctx.to_device(np.ascontiguousarray(x[:, b0 * B:b0 * B + m])), ctx.array((ch, m), np.int16)
+        fe.update(dx, dy, m)
+        got[:, b0 * B:b0 * B + m] = dy.download()
+    for c in range(ch):
+        f = orc.frontend_new(first_conversion=int(x[c, 0]))
+        want = orc.frontend_run(f, x[c])
+        assert np.array_equal(got[c], want), c
+        if c % 17 == 0:
+            _check_state(fe, f, c)
+
+
 def test_frontend_in_place_on_the_slab_pipeline(ctx, orc):
     """in == out (the ADC words are overwritten by the conditioned samples, as the reference's node does with its block): the slab
     pipeline loads slab t + 2 -- and the sample in front of it -- before slab t - 1 is stored"""

@@ -1112,7 +1112,14 @@ struct msdr_biquad_q15 {
     uint32_t channels;
     int *d_defs;      // [channels][32]
     int max_stage;    // highest stage index given to setCoefficients so far (-1: none): stages above 0 chain through the records' flag bits
+    int pipe_ch;      // channels per workgroup of biquad_teensy_pipe4_kernel (64 / 32 / 16), 0: never that kernel (read at create time)
 };
+static int tq4_pipe_ch_at_create(uint32_t channels)
+{
+    if (getenv("MSDR_NO_BIQUAD_PIPE4")) return 0;
+    if (const char *e = getenv("MSDR_BIQUAD_PIPE_CH")) { const int v = atoi(e); if (v == 64 || v == 32 || v == 16) return v; }
+    return tq4_channels_per_group(channels);
+}
 
 // filter_biquad.cpp:84-100 applied to every channel's record
 __global__ void tbq_set_coef_kernel(int *defs, int channels, int stage, int c0, int c1, int c2, int c3, int c4)
@@ -1135,7 +1142,7 @@ extern "C" int msdr_biquad_q15_create(msdr_ctx *ctx, uint32_t channels, msdr_biq
     if (channels == 0) return fail(MSDR_STATUS_ARGUMENT_ERROR, "channels == 0");
     msdr_biquad_q15 *S = new (std::nothrow) msdr_biquad_q15();
     if (!S) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
-    S->ctx = ctx; S->channels = channels; S->d_defs = nullptr; S->max_stage = -1;
+    S->ctx = ctx; S->channels = channels; S->d_defs = nullptr; S->max_stage = -1; S->pipe_ch = tq4_pipe_ch_at_create(channels);
     if (int rc = dzalloc(ctx, (size_t)channels * 32, &S->d_defs)) { delete S; return rc; }   // h:36-39: passes nothing
     *out = S;
     return 0;
@@ -1157,11 +1164,17 @@ extern "C" int msdr_biquad_q15_update(msdr_biquad_q15 *S, q15_t *d_data, uint32_
     if (blockSize == 0) return 0;
     if (!d_data) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
     if (blockSize & 1u) return fail(MSDR_STATUS_LENGTH_ERROR, "AudioFilterBiquad processes sample pairs: blockSize must be even");
-    if (S->max_stage == 0 && (S->channels & 63u) == 0 && (blockSize & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_data) & 15) == 0 && !getenv("MSDR_NO_BIQUAD_PIPE4")) {
-        // one stage, slab-shaped batch: the recursion alone on one wave, the input products element-wise on six more (msdr_kernels.hiph)
-        hipLaunchKernelGGL(biquad_teensy_pipe4_kernel<1>, dim3(S->channels / 64), dim3(kTq4Threads), kTq4LdsBytes, S->ctx->stream, (short *)d_data,
-                           S->d_defs, (int *)nullptr, (int)S->channels, (long long)blockSize);
-        return launch_check("biquad_teensy_pipe4_kernel<1>");
+    if (S->max_stage == 0 && (blockSize & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_data) & 15) == 0 && S->pipe_ch) {
+        // one stage, slab-shaped batch: the recursion alone on one wave, the input products element-wise on the others (msdr_kernels.hiph)
+        const int per_group = S->pipe_ch;
+#define MSDR_TQ4_LAUNCH(CH_)                                                                                                                               \
+        if (per_group == CH_ && S->channels % CH_ == 0) {                                                                                                  \
+            hipLaunchKernelGGL((biquad_teensy_pipe4_kernel<1, CH_>), dim3(S->channels / CH_), dim3(tq4_threads(CH_)), tq4_lds_bytes(CH_), S->ctx->stream,  \
+                               (short *)d_data, S->d_defs, (int *)nullptr, (int)S->channels, (long long)blockSize);                                        \
+            return launch_check("biquad_teensy_pipe4_kernel<1>");                                                                                          \
+        }
+        MSDR_TQ4_LAUNCH(64) MSDR_TQ4_LAUNCH(32) MSDR_TQ4_LAUNCH(16)
+#undef MSDR_TQ4_LAUNCH
     }
     hipLaunchKernelGGL((biquad_teensy_kernel<1>), dim3((S->channels + 63) / 64), dim3(64), 0, S->ctx->stream, d_data, S->d_defs,
                        (int *)nullptr, (int)S->channels, (long long)blockSize);
@@ -2889,10 +2902,20 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
 
     if (c->nnodes == 2) {      // biquad1_dac -> biquad2_dac in one pass over the audio
         const bool slabs = (c->channels & 63u) == 0 && (n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 && !c->no_biquad_pipe;
-        if (slabs && c->nodes[0]->max_stage == 0 && c->nodes[1]->max_stage == 0 && !c->no_biquad_pipe4)
-            // one stage per node (the reference's configuration): the recursions alone on two waves, the input products element-wise on fourteen more
-            hipLaunchKernelGGL(biquad_teensy_pipe4_kernel<2>, dim3(c->channels / 64), dim3(kTq4Threads), kTq4LdsBytes, c->ctx->stream, (short *)d_audio,
-                               c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);
+        const int per_group = c->nodes[0]->pipe_ch ? c->nodes[0]->pipe_ch : 64;
+        if ((n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 && !c->no_biquad_pipe && c->channels % (unsigned)per_group == 0 &&
+            c->nodes[0]->max_stage == 0 && c->nodes[1]->max_stage == 0 && !c->no_biquad_pipe4) {
+            // one stage per node (the reference's configuration): the recursions alone on two waves, the input products element-wise on the others
+            if (per_group == 64)
+                hipLaunchKernelGGL((biquad_teensy_pipe4_kernel<2, 64>), dim3(c->channels / 64), dim3(tq4_threads(64)), tq4_lds_bytes(64), c->ctx->stream, (short *)d_audio,
+                                   c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);
+            else if (per_group == 32)
+                hipLaunchKernelGGL((biquad_teensy_pipe4_kernel<2, 32>), dim3(c->channels / 32), dim3(tq4_threads(32)), tq4_lds_bytes(32), c->ctx->stream, (short *)d_audio,
+                                   c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);
+            else
+                hipLaunchKernelGGL((biquad_teensy_pipe4_kernel<2, 16>), dim3(c->channels / 16), dim3(tq4_threads(16)), tq4_lds_bytes(16), c->ctx->stream, (short *)d_audio,
+                                   c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);
+        }
         else if (slabs)
             hipLaunchKernelGGL(biquad_teensy_pipe_kernel, dim3(c->channels / 64), dim3(128), 0, c->ctx->stream, (short *)d_audio,
                                c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);     // node per wave, slab pipeline

@@ -734,11 +734,13 @@ def test_chain_q15_two_biquad_nodes_pipeline(ctx, orc, golden, ch):
             assert np.array_equal(got[c], want), (ch, c)
 
 
+@pytest.mark.parametrize("per_group", [16, 32, 64])
 @pytest.mark.parametrize("block", [B, 2 * B, 3 * B, None])
-def test_chain_q15_one_stage_nodes_on_the_slab_pipeline(ctx, orc, golden, block):
+def test_chain_q15_one_stage_nodes_on_the_slab_pipeline(ctx, orc, golden, block, per_group, monkeypatch):
     """The reference's configuration -- one stage per node (low-pass .ino:391-393, Q = 15 notch .ino:356) -- on whole 64-channel groups:
     biquad_teensy_pipe4_kernel<2> (the two recursions alone on two waves).  Calls of one, two and three slabs (the pipeline's start-up
     and drain paths) and one long call; full-scale square wave; state carried from call to call."""
+    monkeypatch.setenv("MSDR_BIQUAD_PIPE_CH", str(per_group))      # channels per workgroup (read when the nodes are created)
     rng = np.random.default_rng(7)
     ch, n = 128, 12 * B
     x = rng.integers(-32768, 32768, (ch, n)).astype(np.int16)

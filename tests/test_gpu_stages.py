@@ -241,11 +241,13 @@ def test_biquad_q15_bit_exact(ctx, orc, n_stage):
     assert e.value.status == msdr.STATUS_LENGTH_ERROR
 
 
+@pytest.mark.parametrize("per_group", [16, 32, 64])
 @pytest.mark.parametrize("kind", ["lowpass", "notch"])
-def test_biquad_q15_one_stage_node_on_the_slab_pipeline(ctx, orc, kind):
+def test_biquad_q15_one_stage_node_on_the_slab_pipeline(ctx, orc, kind, per_group, monkeypatch):
     """A one-stage node over a slab-shaped batch (channels a multiple of 64, blocks a multiple of 128: the reference's cadence) runs on
     biquad_teensy_pipe4_kernel<1> -- the recursion alone on one wave, the input products element-wise beside it.  Bit-exact incl. the
     state record, saturation, several calls; a second stage sends the node back to the per-lane kernel."""
+    monkeypatch.setenv("MSDR_BIQUAD_PIPE_CH", str(per_group))      # 16 / 32 / 64 channels per workgroup: the host's rule picks by batch size (read at create time)
     rng = np.random.default_rng(60 + len(kind))
     corr = orclib.AUDIO_SAMPLE_RATE_EXACT / 24000.0
     coef = orc.biquad_design(orclib.BQ_LOWPASS, np.float32(5400 * corr), 0.54) if kind == "lowpass" else orc.biquad_design(orclib.BQ_NOTCH, np.float32(3000 * corr), 15.0)

@@ -755,6 +755,22 @@ def test_chain_q15_one_stage_nodes_on_the_slab_pipeline(ctx, orc, golden, block,
         assert np.array_equal(got[c], want), (block, c)
 
 
+@pytest.mark.parametrize("ch", [16, 48, 80])
+def test_chain_q15_node_slab_pipeline_on_multiples_of_16_channels(ctx, orc, golden, ch):
+    """Small batches take 16 channels per workgroup on the node pipeline: channel counts that are no multiple of 64, every channel checked."""
+    rng = np.random.default_rng(ch)
+    n = 6 * B
+    x = rng.integers(-32768, 32768, (ch, n)).astype(np.int16)
+    taps = golden["fir/taps_am102"]
+    lp = orc.biquad_design(orclib.BQ_LOWPASS, np.float32(5400 * CORR), 0.54)
+    nt = orc.biquad_design(orclib.BQ_NOTCH, np.float32(3000 * CORR), 15.0)
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, taps, taps, mode=orclib.AM, biquad_nodes=[[lp], [nt]])
+    got = run_chain(ctx, chain, x, np.int16, 2 * B)
+    for c in range(ch):
+        want = orc.chain_q15(x[c], orclib.AM, taps, taps, biquads=[orc.biquad_teensy_new([lp]), orc.biquad_teensy_new([nt])])
+        assert np.array_equal(got[c], want), c
+
+
 @pytest.mark.parametrize("variant", ["fs4", "swapped", "minus32768", "gaps", "period8"])
 def test_chain_q15_nco_tables_on_matrix_cores(ctx, orc, golden, variant):
     """AudioEffectFreqConv tables of period 4 with alternating zeros (the node driven at fs/4) run on the matrix-core kernel:

@@ -35,7 +35,7 @@ def _check_state(fe, f_orc, c):
     assert list(buf) == list(f_orc.agc.agc_buffer)
 
 
-@pytest.mark.parametrize("ch,call_blocks", [(1, 40), (64, 7), (70, 1), (130, 13), (128, 3), (192, 80), (64, 1), (64, 2)])   # whole 64-channel groups: the slab pipelines
+@pytest.mark.parametrize("ch,call_blocks", [(1, 40), (64, 7), (70, 1), (130, 13), (128, 3), (192, 80), (64, 1), (64, 2), (16, 5), (48, 2), (80, 3)])   # multiples of 16 channels: the slab pipeline
 @pytest.mark.parametrize("level", [400, 9000, 31000])
 def test_frontend_matches_oracle(ctx, orc, ch, call_blocks, level):
     """Whole front end over many calls (state carried in HBM), channel counts around the 64-lane workgroup, levels that

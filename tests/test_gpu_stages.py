@@ -241,6 +241,26 @@ def test_biquad_q15_bit_exact(ctx, orc, n_stage):
     assert e.value.status == msdr.STATUS_LENGTH_ERROR
 
 
+@pytest.mark.parametrize("ch", [16, 48, 80, 96])
+def test_biquad_q15_slab_pipeline_on_channel_counts_that_are_not_whole_waves(ctx, orc, ch):
+    """Below 8192 channels the slab pipeline takes 16 channels per workgroup: any multiple of 16 channels runs on it (every channel checked)."""
+    rng = np.random.default_rng(ch)
+    corr = orclib.AUDIO_SAMPLE_RATE_EXACT / 24000.0
+    coef = orc.biquad_design(orclib.BQ_NOTCH, np.float32(3000 * corr), 15.0)
+    node = msdr.BiquadQ15(ctx, ch)
+    node.set_coefficients(0, coef)
+    refs = [orc.biquad_teensy_new([coef]) for _ in range(ch)]
+    for nb in (2, 1, 4):
+        x = _rand16(rng, (ch, nb * B), 20000)
+        d = ctx.to_device(x)
+        node.update(d, nb * B)
+        got = d.download()
+        for c in range(ch):
+            assert np.array_equal(got[c], orc.biquad_teensy_update(refs[c], x[c])), (nb, c)
+    for c in range(ch):
+        assert list(node.definition(c)) == list(refs[c].definition), c
+
+
 @pytest.mark.parametrize("per_group", [16, 32, 64])
 @pytest.mark.parametrize("kind", ["lowpass", "notch"])
 def test_biquad_q15_one_stage_node_on_the_slab_pipeline(ctx, orc, kind, per_group, monkeypatch):

@@ -983,6 +983,7 @@ struct msdr_biquad_df1_f32 {
     float *d_state_alt;   // ping-pong partner: a segmented launch reads one and writes the other
     double pole_radius;
     bool sequential;      // ill-conditioned for the parallel evaluation (cascade_condition): biquad_df1_seq_kernel, CMSIS order
+    bool seq_segments;    // sequential kernel: split long blocks of few channels into time segments (MSDR_BIQUAD_SEQ_NO_SEGMENTS, read at init)
     float *d_coeffs;      // sequential: the 5 x stages coefficients
     float *d_seq_scratch; // sequential, few channels x long block: the segments' warm-up samples (biquad_seqseg_gather_kernel)
     size_t seq_scratch_floats;
@@ -1011,6 +1012,7 @@ extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, cons
     S->pole_radius = numStages ? max_pole_radius(pCoeffs, (int)numStages) : 0.0;
     S->d_coeffs = nullptr; S->d_seq_scratch = nullptr; S->seq_scratch_floats = 0;
     S->sequential = numStages > 0 && (cascade_needs_cmsis_order(pCoeffs, (int)numStages) || getenv("MSDR_BIQUAD_SEQUENTIAL"));
+    S->seq_segments = getenv("MSDR_BIQUAD_SEQ_NO_SEGMENTS") == nullptr;
     if (S->sequential) {
         std::vector<float> cf(pCoeffs, pCoeffs + 5 * numStages);
         if (int rc = upload(ctx, cf, &S->d_coeffs)) { delete S; return rc; }
@@ -1038,7 +1040,7 @@ extern "C" int msdr_biquad_df1_f32_process(msdr_biquad_df1_f32 *S, const float32
         // few channels and a long block: one lane per (channel, time segment), each segment warmed up over the samples in front of
         // it (copied aside first, so in place stays allowed); the warm-up length follows from the slowest pole (1e-10 of the state)
         long long nseg = 1, seg_len = blockSize, warm = 0;
-        if (S->channels < 8192 && S->pole_radius > 0.0 && S->pole_radius < 0.99999 && !getenv("MSDR_BIQUAD_SEQ_NO_SEGMENTS")) {
+        if (S->channels < 8192 && S->pole_radius > 0.0 && S->pole_radius < 0.99999 && S->seq_segments) {
             warm = ((long long)std::ceil(std::log(1e-10) / std::log(S->pole_radius)) + 64 * S->stages + 3) & ~3LL;
             const long long min_len = std::max<long long>(8 * warm, 1024);
             const long long want = (65536 + S->channels - 1) / S->channels;

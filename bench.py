@@ -115,6 +115,27 @@ def synth_if(torch, dev, channels, n, seed):
     return x
 
 
+def pick_team(run, xs, modes, ts, limit):
+    """Size of the OpenMP team for the CPU leg: the smallest team whose rate is within 7 % of the best over a ladder of team sizes
+    up to `limit` (= usable_cores()), measured on a short weak-scaling sample (two rows of 2^16 samples per thread).  A lease that
+    is a share of the machine -- by a quota this process cannot see -- shows up here as a rate that stops growing; the record's
+    `cores` is the team that actually ran, never the machine's core count.  Returns (team, {team: Msamples/s})."""
+    ladder = sorted({c for c in (limit, 192, 128, 96, 64, 48, 32, 24, 16, 12, 8, 4, 2, 1) if c <= limit and c <= xs.shape[0]}, reverse=True) or [1]
+    cols = min(xs.shape[1], 1 << 16)
+    rates = {}
+    for t in ladder:
+        rows = min(xs.shape[0], 2 * t)
+        sub = np.ascontiguousarray(xs[:rows, :cols])
+        best = 0.0
+        for _ in range(2):                                     # the first pass of a new team also starts its threads
+            _, dt, _ = run(sub, modes[:rows], ts[:rows], t)
+            best = max(best, rows * cols / dt)
+        rates[t] = best
+    top = max(rates.values())
+    team = min(t for t, r in rates.items() if r >= 0.93 * top)
+    return team, {str(t): round(r / 1e6, 2) for t, r in sorted(rates.items())}
+
+
 def cpu_baseline(wl, x_host, gpu_first, target_s=12.0):
     """Time the oracle (CPU restatement, "port") on a bounded sample of the SAME input: the first
     samples of up to `threads` channels; one-channel workloads are cut into per-thread time chunks
@@ -123,7 +144,7 @@ def cpu_baseline(wl, x_host, gpu_first, target_s=12.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orclib
     orc = orclib.Oracle()
-    threads = os.cpu_count() or 1
+    threads = usable_cores()[0]
     osc_i, osc_q = wl["osc"] if wl["osc"] else (np.array([0, 1, 0, -1], np.float32), np.array([1, 0, -1, 0], np.float32))
     modes_all = wl["modes"] if wl["modes"] is not None else np.full(wl["channels"], wl["mode"], np.int32)
     tapsets_all = wl["tapsets"] if wl["tapsets"] is not None else np.zeros(wl["channels"], np.int32)
@@ -153,6 +174,7 @@ def cpu_baseline(wl, x_host, gpu_first, target_s=12.0):
     else:
         per_row = x_host.shape[1]
         xs, modes, ts = x_host, modes_all[:x_host.shape[0]], tapsets_all[:x_host.shape[0]]
+    threads, ladder = pick_team(run, xs, modes, ts, threads)
     total_dt, passes, outs, used = 0.0, 0, None, 1
     while total_dt < target_s and passes < 50:                # repeat whole passes until ~target_s of wall time
         outs, dt, used = run(xs, modes, ts, threads)
@@ -166,9 +188,12 @@ def cpu_baseline(wl, x_host, gpu_first, target_s=12.0):
         m = min(per_row, gpu_first.shape[1])
         want, got = outs[r, :m].astype(np.float64), gpu_first[r, :m].astype(np.float64)
         worst = max(worst, float(np.sqrt(((got - want) ** 2).sum() / max((want ** 2).sum(), 1e-300))))
-    return {"value": round(rate / 1e6, 3), "unit": "Msamples/s", "cores": int(min(used, xs.shape[0])), "kind": "port",
-            "sample": "%d row(s) x %d samples of the same IF input, %d pass(es), %.1f s wall (oracle/msdr_oracle.c orc_chain_f32; "
-                      "1-thread rate %.2f Msamples/s)" % (xs.shape[0], per_row, passes, total_dt, rate1 / 1e6)}, worst, min(per_row, gpu_first.shape[1])
+    cores = int(min(used, xs.shape[0]))
+    return {"value": round(rate / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "one_thread_Msamples_per_s": round(rate1 / 1e6, 3), "scaling_vs_one_thread": round(rate / (cores * rate1), 3),
+            "team_ladder_Msamples_per_s": ladder,
+            "sample": "%d row(s) x %d samples of the same IF input, %d pass(es), %.1f s wall (oracle/msdr_oracle.c orc_chain_f32; OpenMP team of %d = "
+                      "the smallest team within 7 %% of the best rate on this lease, see team_ladder)" % (xs.shape[0], per_row, passes, total_dt, cores)}, worst, min(per_row, gpu_first.shape[1])
 
 
 def cpu_baseline_q15(wl, x_host, gpu_first, target_s=12.0):
@@ -176,7 +201,7 @@ def cpu_baseline_q15(wl, x_host, gpu_first, target_s=12.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orclib
     orc = orclib.Oracle()
-    threads = os.cpu_count() or 1
+    threads = usable_cores()[0]
     rows = x_host.shape[0]
     n = (x_host.shape[1] // 128) * 128
     modes_all = wl["modes"] if wl["modes"] is not None else np.full(wl["channels"], wl["mode"], np.int32)
@@ -205,6 +230,10 @@ def cpu_baseline_q15(wl, x_host, gpu_first, target_s=12.0):
     else:
         per_row = n
         xs, modes, ts = np.ascontiguousarray(x_host[:, :n]), modes_all[:rows], tapsets_all[:rows]
+    threads, ladder = pick_team(run, xs, modes, ts, threads)
+    cal = np.ascontiguousarray(xs[:1, :min(per_row, 1 << 17)])
+    _, dt1, _ = run(cal, modes[:1], ts[:1], 1)
+    rate1 = cal.size / dt1
     total_dt, passes, outs, used = 0.0, 0, None, 1
     while total_dt < target_s and passes < 50:
         outs, dt, used = run(xs, modes, ts, threads)
@@ -215,9 +244,12 @@ def cpu_baseline_q15(wl, x_host, gpu_first, target_s=12.0):
     bad = 0
     for r in ([0] if rows == 1 else range(xs.shape[0])):
         bad += int((outs[r, :m] != gpu_first[r, :m]).sum())
-    return {"value": round(rate / 1e6, 3), "unit": "Msamples/s", "cores": int(min(used, xs.shape[0])), "kind": "port",
-            "sample": "%d row(s) x %d samples of the same IF input, %d pass(es), %.1f s wall (oracle/msdr_oracle.c orc_chain_q15)"
-                      % (xs.shape[0], per_row, passes, total_dt)}, bad, m
+    cores = int(min(used, xs.shape[0]))
+    return {"value": round(rate / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "one_thread_Msamples_per_s": round(rate1 / 1e6, 3), "scaling_vs_one_thread": round(rate / (cores * rate1), 3),
+            "team_ladder_Msamples_per_s": ladder,
+            "sample": "%d row(s) x %d samples of the same IF input, %d pass(es), %.1f s wall (oracle/msdr_oracle.c orc_chain_q15; OpenMP team of %d)"
+                      % (xs.shape[0], per_row, passes, total_dt, cores)}, bad, m
 
 
 def bench_frontend(args, torch, msdr, ctx, dev, rank, world, dist):
@@ -370,8 +402,33 @@ def bench_spectrum(args, torch, msdr, ctx, dev, rank, world, dist):
     return out
 
 
+def usable_cores():
+    """How many cores this process may really use: the scheduler affinity mask, cut down to the cgroup's CPU quota where one is
+    set (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).  os.cpu_count() is the machine's count, not the lease's: on
+    the GPU box it says 256 while a one-GPU lease is a share of those.  Returns (cores, affinity, quota or None)."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    cores = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return cores, aff, quota
+
+
 def host_info():
-    """nproc and CPU model of the box the CPU baseline runs on."""
+    """CPU model and core counts of the box the CPU baseline runs on: the machine's, and what this process may use."""
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -380,7 +437,8 @@ def host_info():
                 break
     except OSError:
         pass
-    return {"nproc": os.cpu_count() or 1, "cpu_model": model}
+    cores, aff, quota = usable_cores()
+    return {"nproc": os.cpu_count() or 1, "affinity_cores": aff, "cgroup_cpu_quota": quota, "usable_cores": cores, "cpu_model": model}
 
 
 def timed_steps(args, torch, dev, dist, step, after_warmup=None):
@@ -500,22 +558,43 @@ def bench_fir_stage(args, torch, msdr, ctx, dev, rank, world, dist, do_cpu):
     return out
 
 
+def profile_kernel_name(path):
+    """The library kernel a committed profile summary was taken on: its `dominant kernel:` line (tools/prof_summary.py, round 3 on)
+    or, in older summaries, the first msdr:: row of the kernel-stats table.  Returns the name without template arguments."""
+    for line in open(path):
+        if line.startswith("dominant kernel:"):
+            return line.split(":", 1)[1].strip().split("<")[0].replace("void ", "").replace("msdr::", "")
+    for line in open(path):
+        if "msdr::" in line and "calls" in line:
+            return line.split("msdr::", 1)[1].split("<")[0].split("(")[0].strip()
+    return None
+
+
 def attach_traffic(out, tag, args):
     """HBM traffic per launch of the dominant kernel.  The PMC passes cannot run inside this process (rocprofv3 wraps the command),
-    so the figure is the one tools/profile.sh measured for this workload at the commit stamped in the file and committed under
-    profiles/ (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, corrected as MI355X_MICROARCH.md prescribes); null when no such profile
-    is there or the shape was overridden."""
-    if args.samples or args.channels or args.taps or args.stages >= 0 or args.no_mfma:
+    so the figure is the one tools/profile.sh measured for this workload and committed under profiles/ (FETCH_SIZE x 1024 x 2 +
+    WRITE_SIZE x 1024, corrected as MI355X_MICROARCH.md prescribes).  It is attached only when the profile was taken on the kernel
+    THIS run launched (names compared) and the run is the named configuration: any shape override, experiment switch or MSDR_*
+    kernel-selection variable leaves `traffic` null."""
+    if (args.samples or args.channels or args.taps or args.stages >= 0 or args.no_mfma or args.no_fold or args.no_fft
+            or args.time_segments or args.osc_period != 4 or any(k.startswith("MSDR_") and k not in ("MSDR_LIB", "MSDR_BENCH_REHEARSAL") for k in os.environ)):
         return
-    for rnd in ("r02", "r01"):
+    ran = str(out["config"].get("kernel", "")).split("<")[0].split(" ")[0]
+    for rnd in ("r03", "r02", "r01"):
         prof = os.path.join(ROOT, "profiles", rnd, "%s_rocprof_summary.txt" % tag)
         if not os.path.exists(prof):
+            continue
+        pk = profile_kernel_name(prof)
+        if pk is None or pk != ran:
+            out["roofline"]["traffic_note"] = "profiles/%s/%s_rocprof_summary.txt was taken on %s, this run launched %s: not attached" % (rnd, tag, pk, ran)
             continue
         for line in open(prof):
             if line.startswith("HBM traffic per chain_kernel launch") and "total" in line:
                 out["roofline"]["traffic"] = float(line.rsplit("total", 1)[1].split()[0])
-                out["roofline"]["traffic_source"] = "profiles/%s/%s_rocprof_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % (rnd, tag)
-        return
+                out["roofline"]["traffic_source"] = "profiles/%s/%s_rocprof_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on %s)" % (rnd, tag, pk)
+        if out["roofline"]["traffic"] is not None:
+            out["roofline"].pop("traffic_note", None)
+            return
 
 
 def parity_windows(wl, info, x, y, q15, torch):
@@ -633,7 +712,7 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
     torch.cuda.synchronize(dev)
     info = chain.info()
     parity = None
-    first_rows = min(ch, os.cpu_count() or 1)
+    first_rows = min(ch, max(2 * usable_cores()[0], 16))        # IF rows kept for the CPU leg: at least two per thread of its team
     keep = min(n, 1 << 22)                                     # GPU audio kept for the head comparison with the timed CPU sample
     keep_x = min(n, (1 << 26) if ch == 1 else (1 << 22))       # IF sample handed to the CPU baseline
     gpu_first = None
@@ -823,6 +902,24 @@ def make_chain(msdr, ctx, wl, channels, q15, args):
                       biquad_coeffs=wl["bq"] if len(wl["bq"]) else None)
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """Runs this script as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>` in a child
+    process and returns its exit code; the child's stdout (rank 0's one JSON line) and stderr pass straight through."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -846,6 +943,12 @@ def main():
     ap.add_argument("--taps", type=int, default=0, help="experiment: override the tap count (same designer)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks as a CHILD torch.distributed.run job (one process per GPU),
+        # relay its output and exit with its code.  Nothing in this process has touched the GPU yet (torch is not even
+        # imported), and the launcher is a child, never an exec of this process.
+        raise SystemExit(launch_ranks(args.gpus))
+
     import torch
     import msdr
 
@@ -853,7 +956,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (a launcher started another rank count than --gpus says)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the library has no CPU path")
     # MSDR_BENCH_REHEARSAL=1: a dry run of the N>1 control flow on a ONE-GPU box -- every rank on device 0, gloo instead of

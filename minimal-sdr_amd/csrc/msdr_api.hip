@@ -141,10 +141,13 @@ extern "C" int msdr_ctx_create(int device, void *hip_stream, msdr_ctx **out)
     return 0;
 }
 
+void msdr_cmsis_ctx_gone(msdr_ctx *ctx);          // msdr_cmsis.cpp: drops a CMSIS binding (and its objects) that points at this context
+
 extern "C" int msdr_ctx_destroy(msdr_ctx *ctx)
 {
     if (!ctx) return 0;
     if (int rc = bind(ctx)) return rc;
+    msdr_cmsis_ctx_gone(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_fft_tables) (void)hipFree(ctx->d_fft_tables);
@@ -2487,7 +2490,7 @@ static bool chain_post_wanted(const msdr_chain *c, uint32_t ch, bool *pll, int *
 
 // (re)builds the auxiliary chain and the index tables for the current modes / LMS switches; FIR history and oscillator position are
 // taken over from the main chain, PLL and LMS state are per CHANNEL and persist, the post cascade restarts
-static int chain_post_build(msdr_chain *c)
+static int chain_post_build_steps(msdr_chain *c)
 {
     HIP_TRY(hipStreamSynchronize(c->ctx->stream));
     // the cascade state of channels that stay post channels goes with them (df1 stage state: 16 floats per row)
@@ -2499,7 +2502,6 @@ static int chain_post_build(msdr_chain *c)
     }
     chain_post_free(c);
     c->h_post_ch.clear();
-    c->post_mode_gen = c->mode_gen; c->post_anr_gen = c->anr_gen;
     std::vector<int> post_ch, post_src, post_pll, post_anr, virt_row, virt_mode, virt_ts;
     for (uint32_t ch = 0; ch < c->channels; ch++) {
         bool pll; int anr;
@@ -2536,23 +2538,40 @@ static int chain_post_build(msdr_chain *c)
             HIP_TRY(hipMemcpy(c->post_bq->d_state, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
         }
     }
-    c->h_post_ch = post_ch;
     if (int rc = upload(c->ctx, post_ch, &c->d_post_ch)) return rc;
     if (int rc = upload(c->ctx, post_src, &c->d_post_src)) return rc;
     if (int rc = upload(c->ctx, post_pll, &c->d_post_pll)) return rc;
     if (int rc = upload(c->ctx, post_anr, &c->d_post_anr)) return rc;
     if (int rc = upload(c->ctx, virt_row, &c->d_virt_row)) return rc;
-    c->npost = (int)post_ch.size(); c->nvirt = (int)virt_row.size();
-    if (!c->d_post_pll_state) {
-        if (int rc = dzalloc(c->ctx, (size_t)c->channels * 4, &c->d_post_pll_state)) return rc;
+    if (!c->d_post_pll_state) if (int rc = dzalloc(c->ctx, (size_t)c->channels * 4, &c->d_post_pll_state)) return rc;
+    if (!c->d_post_anr_state) {
         std::vector<float> h((size_t)c->channels * kAnrStateFloats, 0.0f);
         for (uint32_t ch = 0; ch < c->channels; ch++) { h[(size_t)ch * kAnrStateFloats] = 120.0f; h[(size_t)ch * kAnrStateFloats + 1] = 0.001f; }   // .ino:715,:718
         if (int rc = upload(c->ctx, h, &c->d_post_anr_state)) return rc;
     }
     // the auxiliary chain continues the main chain's stream: same raw IF history (the newest samples both keep), same table position
-    hipLaunchKernelGGL(post_hist_copy_kernel, dim3(4, c->nvirt), dim3(256), 0, c->ctx->stream, (const int16_t *)c->d_hist[c->cur],
+    hipLaunchKernelGGL(post_hist_copy_kernel, dim3(4, (unsigned)virt_row.size()), dim3(256), 0, c->ctx->stream, (const int16_t *)c->d_hist[c->cur],
                        c->aux->d_hist[c->aux->cur], (const int *)c->d_virt_row, (int)c->hist_len, (int)c->aux->hist_len);
-    return launch_check("post_hist_copy_kernel");
+    if (int rc = launch_check("post_hist_copy_kernel")) return rc;
+    // only a COMPLETE build counts (row counts and the channel list are what chain_post_run and the next rebuild go by)
+    c->h_post_ch = post_ch;
+    c->npost = (int)post_ch.size(); c->nvirt = (int)virt_row.size();
+    return 0;
+}
+
+// The generation stamps are set only after every step succeeded.  A failed build leaves nothing half-made behind (no auxiliary
+// chain, no post cascade, npost = 0) and the stamps stale, so the next msdr_chain_process tries again -- or returns the same error
+// again: PLL / LMS channels never fall back silently to the main kernel's plain AM audio.
+static int chain_post_build(msdr_chain *c)
+{
+    const int rc = chain_post_build_steps(c);
+    if (rc != 0) {
+        chain_post_free(c);
+        c->h_post_ch.clear();
+        return rc;
+    }
+    c->post_mode_gen = c->mode_gen; c->post_anr_gen = c->anr_gen;
+    return 0;
 }
 
 // called by msdr_chain_process (F32) after the main kernel: replaces the rows of the post channels in d_audio

@@ -30,15 +30,36 @@ void remember(const void *S, int kind, void *handle)
     if (it != b.inst.end()) { destroy(it->second); it->second = Entry{kind, handle}; }
     else b.inst.emplace(S, Entry{kind, handle});
 }
-void *lookup(const void *S, int kind)
+// a failed (re-)init: the instance struct already shows the new filter, so the OLD device object must not answer for it any more --
+// later process calls on S do nothing and msdr_last_error() holds the create's text
+void forget(const void *S)
 {
     Binding &b = binding();
-    std::lock_guard<std::mutex> g(b.mu);
+    auto it = b.inst.find(S);
+    if (it != b.inst.end()) { destroy(it->second); b.inst.erase(it); }
+}
+// (caller holds the lock, and keeps it across the process call: a concurrent re-init or msdr_cmsis_bind cannot destroy the object
+//  under a running enqueue -- process calls only queue work on the context's stream, so the lock is held for microseconds)
+void *lookup_locked(const void *S, int kind)
+{
+    Binding &b = binding();
     auto it = b.inst.find(S);
     return (it != b.inst.end() && it->second.kind == kind) ? it->second.handle : nullptr;
 }
 
 }  // namespace
+
+// msdr_ctx_destroy calls this (msdr_api.hip): a context that goes away takes its binding and the objects made through it along,
+// so that no msdr_arm_* call can reach a dangling handle.  Not part of the C ABI.
+__attribute__((visibility("hidden"))) void msdr_cmsis_ctx_gone(msdr_ctx *ctx)
+{
+    Binding &b = binding();
+    std::lock_guard<std::mutex> g(b.mu);
+    if (b.ctx != ctx) return;
+    for (auto &kv : b.inst) destroy(kv.second);
+    b.inst.clear();
+    b.ctx = nullptr; b.channels = 0;
+}
 
 extern "C" int msdr_cmsis_bind(msdr_ctx *ctx, uint32_t channels)
 {
@@ -58,13 +79,14 @@ extern "C" msdr_arm_status msdr_arm_fir_init_q15(msdr_arm_fir_instance_q15 *S, u
     Binding &b = binding();
     std::lock_guard<std::mutex> g(b.mu);
     msdr_fir_q15 *h = nullptr;
-    if (!b.ctx || msdr_fir_q15_create(b.ctx, numTaps, pCoeffs, b.channels, &h) != 0) return MSDR_ARM_MATH_ARGUMENT_ERROR;
+    if (!b.ctx || msdr_fir_q15_create(b.ctx, numTaps, pCoeffs, b.channels, &h) != 0) { forget(S); return MSDR_ARM_MATH_ARGUMENT_ERROR; }
     remember(S, 0, h);
     return MSDR_ARM_MATH_SUCCESS;
 }
 extern "C" void msdr_arm_fir_fast_q15(const msdr_arm_fir_instance_q15 *S, q15_t *pSrc, q15_t *pDst, uint32_t blockSize)
 {
-    if (void *h = lookup(S, 0)) (void)msdr_fir_q15_process((msdr_fir_q15 *)h, pSrc, pDst, blockSize);
+    std::lock_guard<std::mutex> g(binding().mu);
+    if (void *h = lookup_locked(S, 0)) (void)msdr_fir_q15_process((msdr_fir_q15 *)h, pSrc, pDst, blockSize);
 }
 
 extern "C" void msdr_arm_fir_init_f32(msdr_arm_fir_instance_f32 *S, uint16_t numTaps, float32_t *pCoeffs, float32_t *pState, uint32_t blockSize)
@@ -75,10 +97,12 @@ extern "C" void msdr_arm_fir_init_f32(msdr_arm_fir_instance_f32 *S, uint16_t num
     std::lock_guard<std::mutex> g(b.mu);
     msdr_fir_f32 *h = nullptr;
     if (b.ctx && msdr_fir_f32_create(b.ctx, numTaps, pCoeffs, b.channels, &h) == 0) remember(S, 1, h);
+    else forget(S);
 }
 extern "C" void msdr_arm_fir_f32(const msdr_arm_fir_instance_f32 *S, float32_t *pSrc, float32_t *pDst, uint32_t blockSize)
 {
-    if (void *h = lookup(S, 1)) (void)msdr_fir_f32_process((msdr_fir_f32 *)h, pSrc, pDst, blockSize);
+    std::lock_guard<std::mutex> g(binding().mu);
+    if (void *h = lookup_locked(S, 1)) (void)msdr_fir_f32_process((msdr_fir_f32 *)h, pSrc, pDst, blockSize);
 }
 
 extern "C" void msdr_arm_biquad_cascade_df1_init_f32(msdr_arm_biquad_casd_df1_inst_f32 *S, uint8_t numStages, float32_t *pCoeffs, float32_t *pState)
@@ -89,8 +113,10 @@ extern "C" void msdr_arm_biquad_cascade_df1_init_f32(msdr_arm_biquad_casd_df1_in
     std::lock_guard<std::mutex> g(b.mu);
     msdr_biquad_df1_f32 *h = nullptr;
     if (b.ctx && msdr_biquad_df1_f32_create(b.ctx, numStages, pCoeffs, b.channels, &h) == 0) remember(S, 2, h);
+    else forget(S);
 }
 extern "C" void msdr_arm_biquad_cascade_df1_f32(const msdr_arm_biquad_casd_df1_inst_f32 *S, float32_t *pSrc, float32_t *pDst, uint32_t blockSize)
 {
-    if (void *h = lookup(S, 2)) (void)msdr_biquad_df1_f32_process((msdr_biquad_df1_f32 *)h, pSrc, pDst, blockSize);
+    std::lock_guard<std::mutex> g(binding().mu);
+    if (void *h = lookup_locked(S, 2)) (void)msdr_biquad_df1_f32_process((msdr_biquad_df1_f32 *)h, pSrc, pDst, blockSize);
 }

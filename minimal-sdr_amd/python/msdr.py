@@ -201,6 +201,10 @@ class Context:
     def synchronize(self):
         _ck(self.lib.msdr_ctx_synchronize(self.h))
 
+    def stream(self):
+        """The hipStream_t the context enqueues on, as an int (0 = the NULL stream); e.g. msdr_dist.OverlappedGather(compute_stream=...)."""
+        return int(self.lib.msdr_ctx_stream(self.h) or 0)
+
     def array(self, shape, dtype):
         return DeviceArray(self, shape, dtype)
 

@@ -77,11 +77,24 @@ class OverlappedGather:
         og.finish()                       # all gathers done
         og.result(k)                      # gathered audio of block k (k = last or last - 1), on root (all ranks if root is None)
 
-    With RCCL the collective runs on the process group's own stream, ordered after the work already queued on the current
-    stream at submit time -- which is exactly the demodulation of block k."""
+    Stream ordering.  With RCCL the collective runs on the process group's own stream, ordered after the work already queued on
+    torch's CURRENT stream at submit time, and work.wait() makes torch's current stream wait for it.  The demodulation, however,
+    runs on the msdr context's stream (msdr.Context(device) creates its own unless it is handed one).  Pass that stream as
+    `compute_stream` (the hipStream_t from msdr_ctx_stream(), as an int / ctypes pointer, or a torch.cuda.Stream): submit() then
+    makes the current stream wait for the demodulation queued so far before the collective starts, and buffer() makes the compute
+    stream wait for the gather that last read the buffer before block k + 2 overwrites it.  Without `compute_stream` the caller
+    must run the context ON torch's current stream (bench.py does: msdr.Context(dev, stream.cuda_stream)); host tensors (gloo)
+    need no ordering."""
 
-    def __init__(self, total_channels, count, n, dtype, device, root=None, group=None):
+    def __init__(self, total_channels, count, n, dtype, device, root=None, group=None, compute_stream=None):
         self.total, self.root, self.group = int(total_channels), root, group
+        self.cstream = None
+        if compute_stream is not None and torch.device(device).type == "cuda":
+            if isinstance(compute_stream, torch.cuda.Stream):
+                self.cstream = compute_stream
+            else:
+                h = getattr(compute_stream, "value", compute_stream)      # ctypes.c_void_p or int
+                self.cstream = torch.cuda.ExternalStream(int(h), device=device) if h else None   # NULL = the legacy default stream: ordered with everything
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.dtype = dtype
         self.bufs = [torch.zeros((count, n), dtype=dtype, device=device) for _ in range(2)]
@@ -97,12 +110,16 @@ class OverlappedGather:
     def buffer(self, k):
         w = self.work[k & 1]
         if w is not None:
-            w.wait()
+            w.wait()                                  # torch's current stream now waits for the gather
             self.work[k & 1] = None
+            if self.cstream is not None and self.cstream != torch.cuda.current_stream(self.cstream.device):
+                self.cstream.wait_stream(torch.cuda.current_stream(self.cstream.device))      # ... and so does the demodulation of block k
         return self.bufs[k & 1]
 
     def submit(self, k):
         i = k & 1
+        if self.cstream is not None and self.cstream != torch.cuda.current_stream(self.cstream.device):
+            torch.cuda.current_stream(self.cstream.device).wait_stream(self.cstream)          # the demodulation of block k, queued on the context's stream
         send = self.bufs[i].view(torch.uint8)
         if self.send[i] is not None:                  # a shard smaller than the largest: padded copy
             self.send[i][:send.shape[0]] = send

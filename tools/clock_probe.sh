@@ -1,14 +1,18 @@
 #!/usr/bin/env bash
-# tools/clock_probe.sh <tag> [ENV=VAL ...] -- <bench args>: GRBM_GUI_ACTIVE cycles and traced duration of the chain kernel -> effective shader clock
+# tools/clock_probe.sh <tag> [ENV=VAL ...] -- <bench args>: GRBM_GUI_ACTIVE cycles (counter pass) and traced duration (trace pass) of the chain kernel -> effective shader clock
 TAG=$1; shift
 ENVS=()
-while [ "$1" != "--" ]; do ENVS+=("$1"); shift; done; shift
+while [ $# -gt 0 ] && [ "$1" != "--" ]; do ENVS+=("$1"); shift; done
+if [ $# -eq 0 ]; then echo "usage: $0 <tag> [ENV=VAL ...] -- <bench args>" >&2; exit 2; fi
+shift
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 export TMPDIR=/tmp
 OUT=gpurun_out/clk_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 for e in "${ENVS[@]}"; do export "$e"; done
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT" -- python3 bench.py "$@" --no-cpu --no-parity --steps 3 --warmup 1 > "$OUT/log.txt" 2>&1
+# two passes: the counter pass is never combined with a tracing domain (tools/profile.sh), durations come from the trace pass
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- python3 bench.py "$@" --no-cpu --no-parity --steps 3 --warmup 1 > "$OUT/log_trace.txt" 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc" -- python3 bench.py "$@" --no-cpu --no-parity --steps 3 --warmup 1 > "$OUT/log_pmc.txt" 2>&1
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, os, sys
 out, tag = sys.argv[1], sys.argv[2]

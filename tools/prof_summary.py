@@ -14,6 +14,9 @@ print("command: python3 bench.py", args)
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print("\n== kernel stats (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, out))
     rows = list(csv.DictReader(open(f)))
+    lib = [r for r in rows if "msdr::" in r.get("Name", "")]
+    if lib:
+        print("dominant kernel:", lib[0]["Name"].split("(")[0])      # bench.py attach_traffic compares it with the run's config.kernel
     for r in rows[:12]:
         print("  %-70s calls %6s  total %12s ns  avg %12s ns  %5s %%" % (r.get("Name", "")[:70], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
 line = [l for l in open(os.path.join(out, "trace.log")) if l.startswith("{")]

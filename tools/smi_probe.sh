@@ -2,7 +2,9 @@
 # tools/smi_probe.sh <tag> [ENV=VAL ...] -- <bench args>: samples rocm-smi clocks / power while the bench loops
 TAG=$1; shift
 ENVS=()
-while [ "$1" != "--" ]; do ENVS+=("$1"); shift; done; shift
+while [ $# -gt 0 ] && [ "$1" != "--" ]; do ENVS+=("$1"); shift; done
+if [ $# -eq 0 ]; then echo "usage: $0 <tag> [ENV=VAL ...] -- <bench args>" >&2; exit 2; fi
+shift
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 mkdir -p gpurun_out/r02
 ( for e in "${ENVS[@]}"; do export "$e"; done; python3 bench.py "$@" --no-cpu --no-parity --steps ${STEPS:-6000} --warmup 5 > gpurun_out/r02/smi_$TAG.json 2>/dev/null ) &

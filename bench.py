@@ -34,6 +34,19 @@ sys.path.insert(0, os.path.join(ROOT, "minimal-sdr_amd", "python"))
 
 FS = 24000.0
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GUIDE_COPY_GBS = 6290.0        # MI355X_MICROARCH.md:36: "6.29 TB/s measured (float4 copy, 79%)"
+MEASURED_COPY_GBS = 6590.0     # this repo's own best 1:1 read / write stream on the part: one-shot float4 copy, 4 GiB -> 4 GiB, non-temporal loads and
+                               # stores, 1.303 ms (profiles/r03/stream_order.md, tools/probes/copy_ceiling_probe.hip)
+
+
+def ceiling_fracs(roofline):
+    """Adds the fraction against the guide's measured copy rate (SURVEY 8d asks for both denominators) and against the best copy this
+    repo measured itself; `frac` stays achieved / 8 TB/s."""
+    a = roofline["achieved"]
+    roofline["frac_vs_6.29TBps"] = round(a / GUIDE_COPY_GBS, 4)
+    roofline["frac_of_measured_copy"] = round(a / MEASURED_COPY_GBS, 4)
+    roofline["measured_copy_GBps"] = MEASURED_COPY_GBS
+    return roofline
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 matrix peak (same guide)
 
@@ -331,6 +344,7 @@ def bench_frontend(args, torch, msdr, ctx, dev, rank, world, dist):
         out["cpu_baseline"] = {"value": round(xs.size / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
                                "sample": "%d channels x %d samples of the same input (oracle/msdr_oracle.c orc_frontend_run)" % xs.shape}
         out["parity"] = {"mismatching_samples": bad, "tolerance": 0}
+    ceiling_fracs(out["roofline"])
     return out
 
 
@@ -399,6 +413,7 @@ def bench_spectrum(args, torch, msdr, ctx, dev, rank, world, dist):
         out["cpu_baseline"] = {"value": round(k * 128 / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
                                "sample": "%d transforms of the same input through ctypes (oracle/msdr_oracle.c orc_rfft128_q15)" % k}
         out["parity"] = {"mismatching_values": bad, "tolerance": 0}
+    ceiling_fracs(out["roofline"])
     return out
 
 
@@ -555,6 +570,7 @@ def bench_fir_stage(args, torch, msdr, ctx, dev, rank, world, dist, do_cpu):
                                     "sample": "%d windows of the same input incl. pre-roll, through ctypes (oracle/msdr_oracle.c)" % len(keep)}, **host_info())
         out["parity"] = {("mismatching_samples" if q15 else "rel_rms_worst"): float("%.3g" % worst), "tolerance": 0 if q15 else 1e-6,
                          "windows": [{"channel": int(r), "start": int(lo), "length": int(L)} for (r, lo) in keep]}
+    ceiling_fracs(out["roofline"])
     return out
 
 
@@ -887,6 +903,7 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
                                               "rows": int(min(first_rows, max(1, x_host.shape[0]))), "samples_per_row": int(per_row)}
     if parity is not None:
         out["parity"] = parity
+    ceiling_fracs(out["roofline"])
     return out
 
 

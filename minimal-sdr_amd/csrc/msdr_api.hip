@@ -15,6 +15,7 @@
 #include "msdr_chain_q15mf.hiph"
 #include "msdr_fir_f32mf.hiph"
 #include "msdr_fir_f32tr.hiph"
+#include "msdr_fir_f32tq.hiph"
 #include "msdr_chain_amtr.hiph"
 #include "msdr_design.h"
 
@@ -684,6 +685,9 @@ struct msdr_fir_f32 : FirInst<float, float> {
     // taps-in-registers path (msdr_fir_f32tr.hiph, <= ~290 taps): header + the two families of A fragments, or null
     char *d_tr_tab = nullptr;
     int tr_ns = 0, tr_skip1 = 0;
+    // tile queue of fir_f32tq_kernel (msdr_fir_f32tq.hiph): two sets of front counters that alternate between launches, or null
+    unsigned *d_tq_ctr = nullptr;
+    int tq_flip = 0, tq_fronts = 32;
     float input_range = 0.0f;            // 0 = block floating point per tile (default); > 0: a fixed scale for samples below this magnitude
 };
 
@@ -888,6 +892,10 @@ extern "C" int msdr_fir_f32_create(msdr_ctx *ctx, uint16_t numTaps, const float3
                         }
             rc = upload(ctx, tb, &S->d_tr_tab);
             S->tr_ns = trs; S->tr_skip1 = (N <= H - 15) ? 1 : 0;
+            if (!rc && !getenv("MSDR_FIR_NO_TQ")) {
+                rc = dzalloc(ctx, (size_t)2 * kTqMaxFronts * kTqCtrStride, &S->d_tq_ctr);
+                if (const char *e = getenv("MSDR_FIR_TQ_FRONTS")) S->tq_fronts = std::max(1, std::min(kTqMaxFronts, atoi(e)));
+            }
         }
         if (!rc) rc = fir_f32_upload_header(S);
         if (rc) { msdr_fir_f32_destroy(S); *out = nullptr; return rc; }
@@ -910,6 +918,42 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
     if (!d_src || !d_dst) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer");
     if ((const void *)d_src == (const void *)d_dst)
         return fail(MSDR_STATUS_ARGUMENT_ERROR, "FIR process is not in-place (the reference uses separate buffers, Minimal-SDR.ino:574-578)");
+    if (S->d_tr_tab && S->d_tq_ctr && (((long long)blockSize + kTrTile - 1) / kTrTile) * (long long)S->channels < 0x7FFFFFFFll) {
+        // taps in registers, tiles dealt from a queue in address order (msdr_fir_f32tq.hiph): a persistent grid of two workgroups per CU
+        TqParams q;
+        q.x = d_src; q.y = d_dst; q.hist = (const float *)S->d_hist[S->cur]; q.tab = (const char *)S->d_tr_tab;
+        q.n = (long long)blockSize; q.channels = (int)S->channels; q.hist_len = (int)S->hist_len;
+        q.tpr = (unsigned)(((long long)blockSize + kTrTile - 1) / kTrTile);
+        q.tpr_shift = -1;
+        for (int sh = 0; sh < 31; sh++) if (q.tpr == (1u << sh)) q.tpr_shift = sh;
+        q.total = q.tpr * (unsigned)S->channels;
+        const unsigned want = (unsigned)std::min<long long>(2LL * S->ctx->num_cus, ((long long)q.total + 3) / 4);
+        q.fronts = (unsigned)std::max(1, std::min<int>(S->tq_fronts, (int)want));
+        q.per_front = (q.total + q.fronts - 1) / q.fronts;
+        q.ctr = S->d_tq_ctr + (size_t)S->tq_flip * kTqMaxFronts * kTqCtrStride;
+        q.ctr_next = S->d_tq_ctr + (size_t)(S->tq_flip ^ 1) * kTqMaxFronts * kTqCtrStride;
+        q.all_aligned = ((blockSize & 3u) == 0 && (reinterpret_cast<uintptr_t>(d_src) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_dst) & 15) == 0) ? 1 : 0;
+        const unsigned grid = std::max(want, q.fronts);
+        const size_t lds = 4 * tr_wave_bytes(S->tr_ns);
+#define MSDR_TQ_LAUNCH(NS_) case NS_: \
+            if (S->tr_skip1) hipLaunchKernelGGL((fir_f32tq_kernel<NS_, true>), dim3(grid), dim3(256), lds, S->ctx->stream, q); \
+            else hipLaunchKernelGGL((fir_f32tq_kernel<NS_, false>), dim3(grid), dim3(256), lds, S->ctx->stream, q); \
+            break;
+        { KernelTimer kt(S->ctx);
+        switch (S->tr_ns) {
+            MSDR_TQ_LAUNCH(2) MSDR_TQ_LAUNCH(3) MSDR_TQ_LAUNCH(4) MSDR_TQ_LAUNCH(5) MSDR_TQ_LAUNCH(6)
+            MSDR_TQ_LAUNCH(7) MSDR_TQ_LAUNCH(8) MSDR_TQ_LAUNCH(9) MSDR_TQ_LAUNCH(10)
+            default: return fail(MSDR_STATUS_ARGUMENT_ERROR, "fir_f32tq: step count not built");
+        } }
+#undef MSDR_TQ_LAUNCH
+        if (int rc = launch_check("fir_f32tq_kernel")) return rc;
+        S->tq_flip ^= 1;
+        hipLaunchKernelGGL((history_kernel<float>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
+                           d_src, (const float *)S->d_hist[S->cur], S->d_hist[S->cur ^ 1], (long long)blockSize, (int)S->hist_len, (int)S->channels);
+        if (int rc = launch_check("history_kernel")) return rc;
+        S->cur ^= 1;
+        return 0;
+    }
     if (S->d_tr_tab) {
         // taps in registers: 8 waves per CU; segments of >= 8 tiles, enough of them for four rounds of resident waves
         const long long tiles = ((long long)blockSize + kTrTile - 1) / kTrTile;
@@ -965,13 +1009,14 @@ extern "C" const char *msdr_fir_f32_kernel_name(msdr_fir_f32 *S)
 {
     static thread_local char name[64];
     if (!S) return "";
-    if (S->d_tr_tab) snprintf(name, sizeof name, "fir_f32tr_kernel<%d, %s>", S->tr_ns, S->tr_skip1 ? "true" : "false");
+    if (S->d_tr_tab && S->d_tq_ctr) snprintf(name, sizeof name, "fir_f32tq_kernel<%d, %s>", S->tr_ns, S->tr_skip1 ? "true" : "false");
+    else if (S->d_tr_tab) snprintf(name, sizeof name, "fir_f32tr_kernel<%d, %s>", S->tr_ns, S->tr_skip1 ? "true" : "false");
     else snprintf(name, sizeof name, "%s", S->d_fm_tab ? "fir_f32mf_kernel" : "fir_kernel<FirF32>");
     return name;
 }
 extern "C" int msdr_fir_f32_destroy(msdr_fir_f32 *S)
 {
-    if (S) { hipFree(S->d_fm_tab); hipFree(S->d_tr_tab); }
+    if (S) { hipFree(S->d_fm_tab); hipFree(S->d_tr_tab); hipFree(S->d_tq_ctr); }
     return fir_destroy(S);
 }
 

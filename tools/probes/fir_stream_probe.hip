@@ -66,6 +66,76 @@ __global__ __launch_bounds__(256) void fir_stream(const f32x4 *__restrict__ x, f
     if (acc == 123.456f) sink[0] = acc + smem[0];
 }
 
+
+// ORDER 3 (dynamic): persistent waves, the WORKGROUP draws its next four consecutive tiles from the counter of its eighth of the
+// buffer (one atomic per 16 KB; the counters of the eight fronts are 256 bytes apart), wave w takes the w-th of them; exactly one
+// tile (+ halo) of loads in flight per wave: the next tile is requested when the current one has arrived, then the current one is
+// stored (DEPTH 1), or the next request waits until the current tile's stores have been issued (DEPTH 0: nothing overlaps).
+template <int DEPTH, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void fir_stream_queue(const f32x4 *__restrict__ x, f32x4 *__restrict__ y, long long ntiles, unsigned *__restrict__ counters,
+                                                        float *__restrict__ sink)
+{
+    extern __shared__ unsigned char smem[];
+    unsigned *slot = reinterpret_cast<unsigned *>(smem);      // [2]: the group drawn for the next / the one after
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long span = ntiles / 8, base = (long long)(blockIdx.x & 7) * span;
+    const unsigned ngroups = (unsigned)(span / 4);
+    unsigned *ctr = counters + 64 * (blockIdx.x & 7);
+    float acc = 0.0f;
+    f32x4 a[4], b[4], ha = (f32x4)(0.0f), hb = (f32x4)(0.0f);
+    auto draw = [&](int i) {                                   // all four waves call it together
+        if (threadIdx.x == 0) slot[i] = atomicAdd(ctr, 1u);
+        __syncthreads();
+        const unsigned g = slot[i];
+        return g;
+    };
+    auto load = [&](f32x4 (&v)[4], f32x4 &h, unsigned g) {
+        const long long t = base + 4LL * g + wv;
+        if (t > 0) h = ld16<NTL>(x + t * 256 - 64 + lane);
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = ld16<NTL>(x + t * 256 + lane + 64 * j);
+    };
+    auto store = [&](const f32x4 (&v)[4], const f32x4 &h, unsigned g) {
+        const long long t = base + 4LL * g + wv;
+        acc += h[0];
+#pragma unroll
+        for (int j = 0; j < 4; j++) st16<NTS>(y + t * 256 + lane + 64 * j, v[j]);
+    };
+    unsigned ga = draw(0), gb;
+    if (ga < ngroups) {
+        load(a, ha, ga);
+        while (true) {
+            gb = draw(1);
+            if (DEPTH == 1) { if (gb < ngroups) load(b, hb, gb); store(a, ha, ga); }
+            else { store(a, ha, ga); if (gb < ngroups) load(b, hb, gb); }
+            if (gb >= ngroups) break;
+            ga = draw(0);
+            if (DEPTH == 1) { if (ga < ngroups) load(a, ha, ga); store(b, hb, gb); }
+            else { store(b, hb, gb); if (ga < ngroups) load(a, ha, ga); }
+            if (ga >= ngroups) break;
+        }
+    }
+    if (acc == 123.456f) sink[0] = acc;
+}
+
+// reference: ONE-SHOT, one 4 KB tile (+ halo) per wave, four waves per workgroup side by side, workgroups in address order inside
+// each eighth (eight fronts), residency limited by the LDS allocation
+template <bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void fir_stream_oneshot(const f32x4 *__restrict__ x, f32x4 *__restrict__ y, long long ntiles, float *__restrict__ sink)
+{
+    extern __shared__ unsigned char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long span = ntiles / 8, base = (long long)(blockIdx.x & 7) * span;
+    const long long t = base + 4LL * (blockIdx.x >> 3) + wv;
+    f32x4 v[4], h = (f32x4)(0.0f);
+    if (t > 0) h = ld16<NTL>(x + t * 256 - 64 + lane);
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = ld16<NTL>(x + t * 256 + lane + 64 * j);
+#pragma unroll
+    for (int j = 0; j < 4; j++) st16<NTS>(y + t * 256 + lane + 64 * j, v[j]);
+    if (h[0] == 123.456f) sink[0] = h[1] + smem[0];
+}
+
 static hipEvent_t e0, e1;
 template <typename F>
 static void timeit(const char *family, const char *variant, const char *extra, double bytes, F &&launch)
@@ -88,13 +158,14 @@ static void timeit(const char *family, const char *variant, const char *extra, d
     fflush(stdout);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const bool only_dynamic = argc > 1 && atoi(argv[1]) == 1;
     const long long total = 1LL << 30;                   // floats: 4096 channels x 2^18 samples, 4 GiB in + 4 GiB out
     const long long ntiles = total / 1024;               // 2^20 tiles of 4 KB
     const double bytes = 8.0 * (double)total;            // algorithmic: the halo re-reads are overhead
-    float *xb, *yb, *sink;
-    CHECK(hipMalloc(&xb, total * 4)); CHECK(hipMalloc(&yb, total * 4)); CHECK(hipMalloc(&sink, 64));
+    float *xb, *yb, *sink; unsigned *counters;
+    CHECK(hipMalloc(&xb, total * 4)); CHECK(hipMalloc(&yb, total * 4)); CHECK(hipMalloc(&sink, 64)); CHECK(hipMalloc(&counters, 2048));
     CHECK(hipMemset(xb, 1, total * 4)); CHECK(hipMemset(yb, 0, total * 4));
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const f32x4 *x = (const f32x4 *)xb; f32x4 *y = (f32x4 *)yb;
@@ -104,6 +175,7 @@ int main()
     SETUP((fir_stream<1, false, false>)) SETUP((fir_stream<1, false, true>)) SETUP((fir_stream<1, true, true>)) SETUP((fir_stream<1, true, false>))
     SETUP((fir_stream<2, false, false>)) SETUP((fir_stream<2, false, true>)) SETUP((fir_stream<2, true, true>)) SETUP((fir_stream<2, true, false>))
     for (int bpc : {2, 1, 4}) {                         // workgroups per CU (2 = the kernel's residency), kept apart by LDS
+        if (only_dynamic) break;
         const unsigned blocks = 256u * bpc;
         const size_t lds = (size_t)(160 * 1024 / bpc) - 1024;
 #define RUN(ORDER, T, NTL, NTS, NAME) snprintf(extra, sizeof extra, ", \"order\": %d, \"tiles_per_unit\": %d, \"workgroups_per_cu\": %d", ORDER, T, bpc); \
@@ -113,6 +185,22 @@ int main()
         ALLPOL(0, 1)
         for (int T : {1, 2, 4, 8, 16, 64}) { ALLPOL(1, T) }
         for (int T : {1, 2, 4, 8, 16, 64}) { ALLPOL(2, T) }
+    }
+    // dynamic order (workgroup draws) and the one-shot reference, by residency
+#define SETUPQ(K) CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SETUPQ((fir_stream_queue<1, false, false>)) SETUPQ((fir_stream_queue<1, false, true>)) SETUPQ((fir_stream_queue<1, true, true>))
+    SETUPQ((fir_stream_queue<0, false, false>)) SETUPQ((fir_stream_queue<0, false, true>)) SETUPQ((fir_stream_queue<0, true, true>))
+    SETUPQ((fir_stream_oneshot<false, false>)) SETUPQ((fir_stream_oneshot<false, true>)) SETUPQ((fir_stream_oneshot<true, true>))
+    for (int bpc : {1, 2, 3, 4, 6, 8}) {
+        const unsigned blocks = 256u * bpc;
+        const size_t lds = bpc >= 8 ? 1024 : (size_t)(160 * 1024 / bpc) - 1024;
+#define RUNQ(DEPTH, NTL, NTS, NAME) snprintf(extra, sizeof extra, ", \"order\": \"dynamic, workgroup draws 4 tiles\", \"loads_overlap_stores\": %d, \"workgroups_per_cu\": %d", DEPTH, bpc); \
+        timeit("fir stream", NAME, extra, bytes, [&] { CHECK(hipMemsetAsync(counters, 0, 2048, 0)); hipLaunchKernelGGL((fir_stream_queue<DEPTH, NTL, NTS>), dim3(blocks), dim3(256), lds, 0, x, y, ntiles, counters, sink); });
+        RUNQ(1, false, false, "plain loads, plain stores") RUNQ(1, false, true, "plain loads, nt stores") RUNQ(1, true, true, "nt loads, nt stores")
+        RUNQ(0, false, false, "plain loads, plain stores") RUNQ(0, false, true, "plain loads, nt stores") RUNQ(0, true, true, "nt loads, nt stores")
+#define RUNO(NTL, NTS, NAME) snprintf(extra, sizeof extra, ", \"order\": \"one-shot, eight fronts\", \"workgroups_per_cu\": %d", bpc); \
+        timeit("fir stream", NAME, extra, bytes, [&] { hipLaunchKernelGGL((fir_stream_oneshot<NTL, NTS>), dim3((unsigned)(ntiles / 4)), dim3(256), lds, 0, x, y, ntiles, sink); });
+        RUNO(false, false, "plain loads, plain stores") RUNO(false, true, "plain loads, nt stores") RUNO(true, true, "nt loads, nt stores")
     }
     return 0;
 }

@@ -6,8 +6,8 @@ while [ $# -gt 0 ] && [ "$1" != "--" ]; do ENVS+=("$1"); shift; done
 if [ $# -eq 0 ]; then echo "usage: $0 <tag> [ENV=VAL ...] -- <bench args>" >&2; exit 2; fi
 shift
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
-mkdir -p gpurun_out/r02
-( for e in "${ENVS[@]}"; do export "$e"; done; python3 bench.py "$@" --no-cpu --no-parity --steps ${STEPS:-6000} --warmup 5 > gpurun_out/r02/smi_$TAG.json 2>/dev/null ) &
+mkdir -p gpurun_out/r03p
+( for e in "${ENVS[@]}"; do export "$e"; done; python3 bench.py "$@" --no-cpu --no-parity --steps ${STEPS:-6000} --warmup 5 > gpurun_out/r03p/smi_$TAG.json 2>/dev/null ) &
 BP=$!
 sleep ${WAIT:-5}
 for i in 1 2 3 4; do
@@ -16,4 +16,4 @@ for i in 1 2 3 4; do
 done
 wait $BP
 python3 -c "
-import json; d=json.load(open('gpurun_out/r02/smi_$TAG.json')); print('$TAG', 'ms', d['ms_per_step'])"
+import json; d=json.load(open('gpurun_out/r03p/smi_$TAG.json')); print('$TAG', 'ms', d['ms_per_step'])"

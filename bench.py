@@ -592,7 +592,7 @@ def attach_traffic(out, tag, args):
     WRITE_SIZE x 1024, corrected as MI355X_MICROARCH.md prescribes).  It is attached only when the profile was taken on the kernel
     THIS run launched (names compared) and the run is the named configuration: any shape override, experiment switch or MSDR_*
     kernel-selection variable leaves `traffic` null."""
-    if (args.samples or args.channels or args.taps or args.stages >= 0 or args.no_mfma or args.no_fold or args.no_fft
+    if (args.samples or args.channels or args.taps or args.stages >= 0 or args.no_mfma or args.no_fold
             or args.time_segments or args.osc_period != 4 or any(k.startswith("MSDR_") and k not in ("MSDR_LIB", "MSDR_BENCH_REHEARSAL") for k in os.environ)):
         return
     ran = str(out["config"].get("kernel", "")).split("<")[0].split(" ")[0]
@@ -717,7 +717,7 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
         chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, wl["ci"], wl["cq"], mixer=wl["mixer"], mode=wl["mode"], modes=wl["modes"],
                            tapsets=wl["tapsets"], osc_i=wl["osc"][0] if wl["osc"] else None, osc_q=wl["osc"][1] if wl["osc"] else None,
                            biquad_coeffs=wl["bq"] if len(wl["bq"]) else None, time_segments=args.time_segments,
-                           flags=(msdr.CHAIN_NO_TAP_FOLDING if args.no_fold else 0) | (msdr.CHAIN_NO_FFT if args.no_fft else 0)
+                           flags=(msdr.CHAIN_NO_TAP_FOLDING if args.no_fold else 0)
                            | (msdr.CHAIN_NO_MFMA if args.no_mfma else 0))
     x = synth_if(torch, dev, ch, n, wl["seed"])
     y = torch.empty((ch, n), dtype=torch.int16 if q15 else torch.float32, device=dev)
@@ -852,9 +852,6 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
     flop_written = 4.0 * wl["taps"] + extra                      # as the reference writes it: two N-tap FIRs
     folded = info["kernel"].startswith("chain_fold")
     flop_exec = (2.0 if folded else 4.0) * info["taps_padded"] + extra     # what the kernel executes (tap folding halves the MACs)
-    if info["kernel"].startswith("chain_fft"):                             # overlap-save: 2 complex 4096-point FFTs (5 F log2 F each) + pointwise
-        F = 4096.0                                                         # product (6 F) + mixer (2 F) per block of `tile` outputs
-        flop_exec = (2 * 5 * F * 12 + 8 * F) / info["tile"] + 4 + 9 * len(wl["bq"])
     out = {
         "metric": "Msamples/s through IF->I/Q->FIR->demod->IIR chain; achieved HBM GB/s vs peak",
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -950,7 +947,6 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (the windowed parity check stays unless --no-parity)")
     ap.add_argument("--no-parity", dest="parity", action="store_false", help="skip the in-run parity check too")
     ap.add_argument("--no-fold", action="store_true", help="keep mixer and FIR as separate arithmetic steps")
-    ap.add_argument("--no-fft", action="store_true", help="never use the overlap-save FFT kernel")
     ap.add_argument("--no-mfma", action="store_true", help="keep the folded FIR on the fp32 VALU (no split-fp16 matrix-core kernel)")
     ap.add_argument("--time-segments", type=int, default=0)
     ap.add_argument("--arith", default="f32", choices=["f32", "q15"],

@@ -165,9 +165,16 @@ int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, float32_t *d_d
 int msdr_fir_f32_reset(msdr_fir_f32 *S);
 const char *msdr_fir_f32_kernel_name(msdr_fir_f32 *S);      /* the kernel msdr_fir_f32_process launches for this instance */
 /* Filters of 16..513 taps run on the matrix cores with the samples as two fp16 pieces (22 bits) after a power-of-two scale.  By
- * default the scale is chosen per 1024-sample tile from the data (block floating point): nothing to declare.  max_abs > 0 pins
+ * default the scale is chosen per 1024-output tile from the data (block floating point): nothing to declare.  max_abs > 0 pins
  * one scale for samples below that magnitude (saves the per-tile maximum; samples above it would overflow); 0 = automatic again.
- * No counterpart in CMSIS (arm_fir_f32 is plain fp32). */
+ * No counterpart in CMSIS (arm_fir_f32 is plain fp32).
+ * Guaranteed precision (arm_fir_f32 has none that depends on the input; this does, and here is the bound).  Let Mw be the largest
+ * magnitude among the samples a tile's outputs can meet (its 1024 samples and the numTaps - 1 before them).  Every sample x of that
+ * window enters the products with an error of at most max(2^-21 |x|, 2^-39 Mw), every tap h with at most max(2^-21 |h|, 2^-38 hmax),
+ * the sums are fp32.  So a sample keeps its full 22 bits down to 2^-18 of Mw; below that it keeps 22 - (R - 18) bits at 2^-R of Mw
+ * (19 bits one part in a million below the tile's peak).  An isolated spike therefore costs the quiet outputs of ITS OWN tile window a
+ * relative 2^-19 ... 2^-15 for spikes 10^6 ... 10^7 times the quiet level, never the stretches before or after that window
+ * (tests/test_gpu_stages.py: test_fir_f32_isolated_spike, test_fir_f32_matrix_core_input_ranges). */
 int msdr_fir_f32_set_input_range(msdr_fir_f32 *S, float max_abs);
 int msdr_fir_f32_destroy(msdr_fir_f32 *S);
 
@@ -352,13 +359,11 @@ typedef struct {
     uint32_t flags;                  /* MSDR_CHAIN_* */
 } msdr_chain_config;
 #define MSDR_CHAIN_NO_TAP_FOLDING 1u /* F32: keep mixer and FIR pair as separate arithmetic steps (as written) */
-#define MSDR_CHAIN_NO_FFT 4u         /* F32: never use the overlap-save FFT kernel (long FIRs stay sliding dot products) */
 #define MSDR_CHAIN_NO_MFMA 8u        /* never run the FIR on the matrix cores (F32: split-fp16 MFMA kernel; Q15: byte-split i8 MFMA kernel) */
 #define MSDR_CHAIN_FOLD_ANY_PERIOD 64u /* F32, NCO: fold the mixer into the taps (matrix-core kernel) also when the oscillator table's only period is its
                                          own length (8, 16 or 32 samples); a table that repeats within its length with period 1 .. 32 is folded by default */
 #define MSDR_CHAIN_SYNCAM_PLL 32u    /* SYNCAM channels run the PLL demodulator (.ino:631-688) instead of the AM branch.  Q15: as the reference, on the int16
                                        FIR outputs.  F32 (an extension): the same loop on the fp32 FIR outputs, audio = corr[0] untruncated */
-#define MSDR_CHAIN_MFMA_WG 16u       /* F32: matrix-core kernel with workgroup tiles (msdr_chain_mfma.hiph) instead of one wave per stream */
 
 typedef struct msdr_chain msdr_chain;
 int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_chain **out);

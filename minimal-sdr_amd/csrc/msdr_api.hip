@@ -6,7 +6,6 @@
 #include "../../include/msdr.h"
 #include "msdr_kernels.hiph"
 #include "msdr_chain_fold.hiph"
-#include "msdr_chain_fft.hiph"
 #include <type_traits>
 #include "msdr_chain_mfma.hiph"
 #include "msdr_chain_mfw.hiph"
@@ -583,7 +582,6 @@ static bool cascade_needs_cmsis_order(const float *coeffs, int stages)
     // three and four sections: the stage fuzz still found 2e-5 ... 6e-5 between kappa 20 and 30 (the test cascades of that size: 13-14)
     const double klimit = stages >= 3 ? 20.0 : kCascadeConditionLimit;
     const bool seq = kappa > klimit || kappa * noise > kCascadeParallelErrorLimit || noise > kCascadeNoiseLimit;
-    if (getenv("MSDR_DEBUG_CONDITION")) fprintf(stderr, "msdr: cascade of %d sections: kappa %.3g, fp32 noise %.3g -> %s\n", stages, kappa, noise, seq ? "CMSIS order" : "parallel");
     return seq;
 }
 
@@ -687,7 +685,7 @@ struct msdr_fir_f32 : FirInst<float, float> {
     int tr_ns = 0, tr_skip1 = 0;
     // tile queue of fir_f32tq_kernel (msdr_fir_f32tq.hiph): two sets of front counters that alternate between launches, or null
     unsigned *d_tq_ctr = nullptr;
-    int tq_flip = 0, tq_fronts = 32;
+    int tq_flip = 0, tq_fronts = 32;     // 32 fronts: 24 ... 64 within 1 %, 16 and fewer saturate the counters (profiles/r03/fir_ab.txt)
     float input_range = 0.0f;            // 0 = block floating point per tile (default); > 0: a fixed scale for samples below this magnitude
 };
 
@@ -772,7 +770,7 @@ extern "C" int msdr_fir_q15_create(msdr_ctx *ctx, uint16_t numTaps, const q15_t 
         return fail(MSDR_STATUS_ARGUMENT_ERROR, "arm_fir_init_q15: numTaps must be even (got %u)", (unsigned)numTaps);
     if (int rc = fir_create<msdr_fir_q15, int16_t, int32_t>(ctx, numTaps, pCoeffs, channels, out)) return rc;
     msdr_fir_q15 *S = *out;
-    if (qm_halo((int)numTaps) <= 512 && !getenv("MSDR_FIR_NO_MFMA")) {       // the same filter on the integer matrix cores (msdr_chain_q15mf.hiph)
+    if (qm_halo((int)numTaps) <= 512) {       // the same filter on the integer matrix cores (msdr_chain_q15mf.hiph)
         const int16_t *ci[1] = {pCoeffs};
         const int par[2] = {0, 1};
         QmTables T;
@@ -855,7 +853,7 @@ extern "C" int msdr_fir_f32_create(msdr_ctx *ctx, uint16_t numTaps, const float3
     double maxabs = 0.0;
     bool finite = true;
     for (int k = 0; k < N; k++) { maxabs = std::max(maxabs, std::fabs((double)pCoeffs[k])); finite = finite && std::isfinite(pCoeffs[k]); }
-    if (N >= 16 && H <= 512 && finite && maxabs > 0.0 && !getenv("MSDR_FIR_NO_MFMA") && fm_lds_bytes(H, ns, 1) <= 160 * 1024) {
+    if (N >= 16 && H <= 512 && finite && maxabs > 0.0 && fm_lds_bytes(H, ns, 1) <= 160 * 1024) {
         int ex = 0;
         (void)std::frexp(maxabs, &ex);
         ex = 14 - ex;                                             // maxabs 2^ex in [2^13, 2^14)
@@ -874,7 +872,7 @@ extern "C" int msdr_fir_f32_create(msdr_ctx *ctx, uint16_t numTaps, const float3
         int rc = upload(ctx, blob, &S->d_fm_tab);
         S->fm_halo_ = H; S->fm_bsteps = ns; S->fm_ex = ex;
         const int trs = tr_steps(N);
-        if (!rc && trs <= kTrMaxSteps && !getenv("MSDR_FIR_NO_TR")) {
+        if (!rc && trs <= kTrMaxSteps) {
             // A fragments of v_mfma_f32_16x16x32_f16 (lane l: row a = l & 15, k = 8 (l >> 4) + j): T_F(s)[a][k'] = the tap at delay
             // H + 16 F + a - k', k' = 32 s + 8 (l >> 4) + j; family F serves the sub-tiles a0 = 16 F and 32 + 16 F (one step later)
             std::vector<char> tb(tr_table_bytes(trs), 0);
@@ -892,10 +890,7 @@ extern "C" int msdr_fir_f32_create(msdr_ctx *ctx, uint16_t numTaps, const float3
                         }
             rc = upload(ctx, tb, &S->d_tr_tab);
             S->tr_ns = trs; S->tr_skip1 = (N <= H - 15) ? 1 : 0;
-            if (!rc && !getenv("MSDR_FIR_NO_TQ")) {
-                rc = dzalloc(ctx, (size_t)2 * kTqMaxFronts * kTqCtrStride, &S->d_tq_ctr);
-                if (const char *e = getenv("MSDR_FIR_TQ_FRONTS")) S->tq_fronts = std::max(1, std::min(kTqMaxFronts, atoi(e)));
-            }
+            if (!rc) rc = dzalloc(ctx, (size_t)2 * kTqMaxFronts * kTqCtrStride, &S->d_tq_ctr);
         }
         if (!rc) rc = fir_f32_upload_header(S);
         if (rc) { msdr_fir_f32_destroy(S); *out = nullptr; return rc; }
@@ -954,35 +949,6 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
         S->cur ^= 1;
         return 0;
     }
-    if (S->d_tr_tab) {
-        // taps in registers: 8 waves per CU; segments of >= 8 tiles, enough of them for four rounds of resident waves
-        const long long tiles = ((long long)blockSize + kTrTile - 1) / kTrTile;
-        long long nseg = (8192 + S->channels - 1) / S->channels;
-        nseg = std::max<long long>(1, std::min<long long>(nseg, std::max<long long>(1, tiles / 8)));
-        const long long seg_len = ((tiles + nseg - 1) / nseg) * kTrTile;
-        nseg = ((long long)blockSize + seg_len - 1) / seg_len;
-        const unsigned grid = (unsigned)(((long long)S->channels * nseg + 3) / 4);
-        const size_t lds = 4 * tr_wave_bytes(S->tr_ns);
-#define MSDR_TR_LAUNCH(NS_) case NS_: \
-            if (S->tr_skip1) hipLaunchKernelGGL((fir_f32tr_kernel<NS_, true>), dim3(grid), dim3(256), lds, S->ctx->stream, d_src, d_dst, \
-                (const float *)S->d_hist[S->cur], (const char *)S->d_tr_tab, (long long)blockSize, (int)S->channels, (int)nseg, seg_len, (int)S->hist_len); \
-            else hipLaunchKernelGGL((fir_f32tr_kernel<NS_, false>), dim3(grid), dim3(256), lds, S->ctx->stream, d_src, d_dst, \
-                (const float *)S->d_hist[S->cur], (const char *)S->d_tr_tab, (long long)blockSize, (int)S->channels, (int)nseg, seg_len, (int)S->hist_len); \
-            break;
-        { KernelTimer kt(S->ctx);
-        switch (S->tr_ns) {
-            MSDR_TR_LAUNCH(2) MSDR_TR_LAUNCH(3) MSDR_TR_LAUNCH(4) MSDR_TR_LAUNCH(5) MSDR_TR_LAUNCH(6)
-            MSDR_TR_LAUNCH(7) MSDR_TR_LAUNCH(8) MSDR_TR_LAUNCH(9) MSDR_TR_LAUNCH(10)
-            default: return fail(MSDR_STATUS_ARGUMENT_ERROR, "fir_f32tr: step count not built");
-        } }
-#undef MSDR_TR_LAUNCH
-        if (int rc = launch_check("fir_f32tr_kernel")) return rc;
-        hipLaunchKernelGGL((history_kernel<float>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
-                           d_src, (const float *)S->d_hist[S->cur], S->d_hist[S->cur ^ 1], (long long)blockSize, (int)S->hist_len, (int)S->channels);
-        if (int rc = launch_check("history_kernel")) return rc;
-        S->cur ^= 1;
-        return 0;
-    }
     const int H = S->fm_halo_, ns = S->fm_bsteps;
     const long long tiles = ((long long)blockSize + kFmTile - 1) / kFmTile;
     long long nseg = (8192 + S->channels - 1) / S->channels;                       // two rounds of 16 waves per CU, >= two tiles per segment
@@ -1010,7 +976,6 @@ extern "C" const char *msdr_fir_f32_kernel_name(msdr_fir_f32 *S)
     static thread_local char name[64];
     if (!S) return "";
     if (S->d_tr_tab && S->d_tq_ctr) snprintf(name, sizeof name, "fir_f32tq_kernel<%d, %s>", S->tr_ns, S->tr_skip1 ? "true" : "false");
-    else if (S->d_tr_tab) snprintf(name, sizeof name, "fir_f32tr_kernel<%d, %s>", S->tr_ns, S->tr_skip1 ? "true" : "false");
     else snprintf(name, sizeof name, "%s", S->d_fm_tab ? "fir_f32mf_kernel" : "fir_kernel<FirF32>");
     return name;
 }
@@ -1043,7 +1008,7 @@ extern "C" int msdr_biquad_df1_f32_cascade_info(uint8_t numStages, const float32
     if (numStages && !pCoeffs) return fail(MSDR_STATUS_ARGUMENT_ERROR, "pCoeffs is null");
     if (kappa) *kappa = cascade_condition(pCoeffs, (int)numStages);
     if (fp32_noise) *fp32_noise = numStages ? cascade_fp32_noise(pCoeffs, (int)numStages) : 0.0;
-    if (cmsis_order) *cmsis_order = (numStages && (cascade_needs_cmsis_order(pCoeffs, (int)numStages) || getenv("MSDR_BIQUAD_SEQUENTIAL"))) ? 1 : 0;
+    if (cmsis_order) *cmsis_order = (numStages && cascade_needs_cmsis_order(pCoeffs, (int)numStages)) ? 1 : 0;
     return 0;
 }
 extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, const float32_t *pCoeffs, uint32_t channels,
@@ -1059,8 +1024,8 @@ extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, cons
     S->ctx = ctx; S->channels = channels; S->stages = numStages; S->d_tabs = nullptr; S->d_state = nullptr; S->d_state_alt = nullptr;
     S->pole_radius = numStages ? max_pole_radius(pCoeffs, (int)numStages) : 0.0;
     S->d_coeffs = nullptr; S->d_seq_scratch = nullptr; S->seq_scratch_floats = 0;
-    S->sequential = numStages > 0 && (cascade_needs_cmsis_order(pCoeffs, (int)numStages) || getenv("MSDR_BIQUAD_SEQUENTIAL"));
-    S->seq_segments = getenv("MSDR_BIQUAD_SEQ_NO_SEGMENTS") == nullptr;
+    S->sequential = numStages > 0 && cascade_needs_cmsis_order(pCoeffs, (int)numStages);
+    S->seq_segments = true;
     if (S->sequential) {
         std::vector<float> cf(pCoeffs, pCoeffs + 5 * numStages);
         if (int rc = upload(ctx, cf, &S->d_coeffs)) { delete S; return rc; }
@@ -1166,7 +1131,6 @@ struct msdr_biquad_q15 {
 };
 static int tq4_pipe_ch_at_create(uint32_t channels)
 {
-    if (getenv("MSDR_NO_BIQUAD_PIPE4")) return 0;
     if (const char *e = getenv("MSDR_BIQUAD_PIPE_CH")) { const int v = atoi(e); if (v == 64 || v == 32 || v == 16) return v; }
     return tq4_channels_per_group(channels);
 }
@@ -1353,7 +1317,7 @@ extern "C" int msdr_frontend_create(msdr_ctx *ctx, uint32_t channels, msdr_front
     // One workgroup walks its channels' stream alone and its step time is the recursion's latency whether 64, 32 or 16 lanes of the recursion
     // wave carry a channel -- only the element-wise work beside it grows with the channel count.  So: as few channels per workgroup as still
     // give every CU one (MI355X: 256 CUs); from 16 384 channels on the CUs are full and 64 per workgroup issue the fewest instructions.
-    fe->pipe_ch = getenv("MSDR_NO_FRONTEND_PIPE") ? -1 : getenv("MSDR_NO_FRONTEND_PIPE4") ? 0 : channels >= 16384 ? 64 : channels >= 8192 ? 32 : 16;
+    fe->pipe_ch = channels >= 16384 ? 64 : channels >= 8192 ? 32 : 16;
     if (const char *e = getenv("MSDR_FRONTEND_PIPE_CH")) { const int v = atoi(e); if (v == 64 || v == 32 || v == 16) fe->pipe_ch = v; }
     std::vector<int> h((size_t)channels * kFeStateInts, 0);
     const float agc_start = 0.25f;                       // Minimal-SDR.ino:94
@@ -1699,19 +1663,12 @@ struct msdr_chain {
     int *d_fset;                      // [channels]
     BiquadCascadeTables<kFoldR> *d_bq_fold;
     std::vector<int> h_mode, h_tapset;
-    // overlap-save FFT path (msdr_chain_fft.hiph)
-    int fft_LP;                       // 0 = not eligible; else outputs per lane (15: N <= 257, 14: N <= 513)
-    std::vector<char> fft_am_ok;      // per tap set: AM may use the FFT path (both branches share the taps)
-    float *d_fft_h, *d_fft_tw;
-    void *d_bq_fft;
     // matrix-core path (msdr_chain_mfma.hiph): any short-period oscillator, any mode
-    bool no_biquad_pipe, no_biquad_pipe4;                 // MSDR_NO_BIQUAD_PIPE / MSDR_NO_BIQUAD_PIPE4, read once at creation (A/B switches for the node pipelines)
     bool mf_ok;
     int mf_halo, mf_bsteps, mf_stride;
     char *d_mf_tab;
     BiquadCascadeTables<kMfL> *d_bq_mf;
     BiquadCascadeTables<32> *d_bq_mf32;
-    int mf_waves;
     // wave-stream variant (msdr_chain_mfw.hiph): waves per workgroup, resident waves per CU, unit table and its cache key
     uint32_t flags;
     int mfw_nw, mfw_waves_per_cu;
@@ -1791,7 +1748,7 @@ static void chain_free(msdr_chain *c)
     hipFree(c->d_taps); hipFree(c->d_osc); hipFree(c->d_mode); hipFree(c->d_tapset);
     hipFree(c->d_hist[0]); hipFree(c->d_hist[1]); hipFree(c->d_bq); hipFree(c->d_bq_state);
     hipFree(c->d_ftaps); hipFree(c->d_fset); hipFree(c->d_bq_fold);
-    hipFree(c->d_fft_h); hipFree(c->d_fft_tw); hipFree(c->d_bq_fft); hipFree(c->d_mf_tab); hipFree(c->d_bq_mf); hipFree(c->d_bq_mf32);
+    hipFree(c->d_mf_tab); hipFree(c->d_bq_mf); hipFree(c->d_bq_mf32);
     hipFree(c->d_bq_state_alt); hipFree(c->d_units); hipFree(c->d_mw_iir); hipFree(c->d_qm_tab); hipFree(c->d_qm_order); hipFree(c->d_at_tab);
     for (int k = 0; k < 2; k++) if (c->nodes[k]) msdr_biquad_q15_destroy(c->nodes[k]);
     if (c->seq_bq) msdr_biquad_df1_f32_destroy(c->seq_bq);
@@ -1830,7 +1787,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     if (!mode_ok(cfg->default_mode)) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad default_mode");
 
     if (f32 && cfg->num_biquad_stages &&
-        (cascade_needs_cmsis_order(cfg->biquad_coeffs, (int)cfg->num_biquad_stages) || getenv("MSDR_BIQUAD_SEQUENTIAL"))) {
+        cascade_needs_cmsis_order(cfg->biquad_coeffs, (int)cfg->num_biquad_stages)) {
         // the parallel "numerators first" evaluation would lose accuracy on this cascade (cascade_condition): build the chain without
         // it and run arm_biquad_cascade_df1_f32 as written behind the main kernel (one lane per channel)
         msdr_chain_config plain = *cfg;
@@ -1849,13 +1806,6 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->ctx = ctx; c->arith = cfg->arith; c->mixer = cfg->mixer; c->sqrt_kind = cfg->sqrt_kind;
     c->channels = cfg->channels; c->ntaps = cfg->num_taps; c->ntaps_pad = (cfg->num_taps + 3u) & ~3u;
     c->hist_len = c->ntaps_pad - 1; c->tapsets = cfg->num_tapsets;
-    c->fft_LP = 0;
-    // measured crossover on MI355X: the FFT kernel's cost does not depend on N, the sliding dot product's
-    // grows by ~0.02 ms per tap per 2^30 samples; they meet near 250 taps
-    if (f32 && !(cfg->flags & MSDR_CHAIN_NO_FFT) && cfg->num_taps >= 248 && cfg->num_taps <= 513) {
-        c->fft_LP = (cfg->num_taps <= 257) ? 15 : 14;
-        c->hist_len = std::max<uint32_t>(c->hist_len, (uint32_t)(kFftF - kThreads * c->fft_LP));   // the FFT block's history
-    }
     if (f32 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && mf_halo((int)(cfg->num_taps + 2 * cfg->num_biquad_stages)) <= 2048)      // the matrix-core kernel's window halo
         c->hist_len = std::max<uint32_t>(c->hist_len, (uint32_t)mf_halo((int)(cfg->num_taps + 2 * cfg->num_biquad_stages)));
     c->osc_len = (cfg->mixer == MSDR_MIXER_NCO) ? cfg->osc_len : 4;
@@ -1866,7 +1816,6 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     c->pole_radius = c->nstages ? max_pole_radius(cfg->biquad_coeffs, (int)c->nstages) : 0.0;
     c->cur = 0; c->phase = 0; c->timing = false; c->timed_ms = 0; c->timed_launches = 0;
     c->gen = 1; c->dh_cache.resize(c->channels); c->dh_gen.assign(c->channels, 0);
-    c->no_biquad_pipe = getenv("MSDR_NO_BIQUAD_PIPE") != nullptr; c->no_biquad_pipe4 = getenv("MSDR_NO_BIQUAD_PIPE4") != nullptr;
     c->flags = cfg->flags; c->mfw_nw = 0; c->mfw_waves_per_cu = 0; c->d_bq_state_alt = nullptr; c->d_mw_iir = nullptr; c->d_units = nullptr; c->units_cap = 0;
     c->mode_gen = 1; c->units_mode_gen = 0; c->units_nseg = 0; c->units_wgs = 0; c->units_wgs_ssb = 0; c->mfw_ssb_fold = false; c->mfw_am_fold = false; c->units_tiles = -1;
     c->part_nseg[0] = c->part_nseg[1] = 1; c->part_seg_len[0] = c->part_seg_len[1] = 0;
@@ -2009,7 +1958,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         c->mf_P = (int)oc.size();
         // no short period: every AudioEffectFreqConv table still repeats with the block (128 entries, freq_conv.cpp:67-103) -- the
         // matrix-core kernel then stages the two mixer products as full-rate streams and runs both FIRs over every sample
-        // (up to 247 taps: from 248 on the overlap-save FFT kernel takes any table at a cost that does not double with a second stream)
+        // (up to 247 taps: beyond that the window does not fit next to the fragments; chain_kernel<ArithF32> takes those)
         c->mf_fr = oc.empty() && cfg->mixer == MSDR_MIXER_NCO && cfg->osc_len > 0 && (128 % cfg->osc_len) == 0 && c->ntaps < 248;
         if (c->mf_fr) c->mf_P = 1;                             // one table per (tap set, flavour): the oscillator is not in it
         if (oc.size() > 4) oc.clear();                         // no VALU fold tables beyond period 4
@@ -2087,7 +2036,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         // product.  What is left per row is the response R sigma to the state sigma at the row's start (cascade basis:
         // (w_s[-1], w_s[-2]) per section) and the row-to-row recurrence sigma' = z + M sigma; see MwIirConsts.
         const int S_ = (int)c->nstages, NS = 2 * S_;
-        bool iirfold = (S_ == 1 || S_ == 2) && !(cfg->flags & MSDR_CHAIN_MFMA_WG) && !getenv("MSDR_NO_IIRFOLD");
+        bool iirfold = (S_ == 1 || S_ == 2);
         bool amfold = false;
         double gap[32] = {0}, sec_a1[2] = {0, 0}, sec_a2[2] = {0, 0}, gl1[2] = {0, 0}, Rmax = 0.0;
         std::vector<float> iirc;
@@ -2183,7 +2132,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                     for (int t = 0; t + k < (int)cnum.size() && t <= m; t++) a += gap[m - t] * cnum[t + k];
                     Rd[m][4 - k] = a; Lmax = std::max(Lmax, std::fabs(a));          // element j = 4 - k: the row's inputs 28..31 in order
                 }
-            amfold = iirfold && Lmax * std::ldexp(1.0, kMwIirEnvExp) < 60000.0 && !getenv("MSDR_NO_AMFOLD");
+            amfold = iirfold && Lmax * std::ldexp(1.0, kMwIirEnvExp) < 60000.0;
             _Float16 *lf = reinterpret_cast<_Float16 *>(iirc.data() + kMwIirLfrag), *df = reinterpret_cast<_Float16 *>(iirc.data() + kMwIirDfrag);
             for (int st2 = 0; st2 < 2; st2++)
                 for (int l = 0; l < 64; l++)
@@ -2340,9 +2289,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                     bsteps = std::max(bsteps, ns);
                 }
         }
-        // workgroup shape: 4 waves if three such workgroups fit a CU's LDS, else 8 waves (the B fragments are shared by more rows)
-        const int nw = (mf_lds_bytes(H, bsteps, 4) * 3 <= 160 * 1024) ? 4 : 8;
-        if (ok && bsteps > 0 && mf_lds_bytes(H, bsteps, nw) <= 160 * 1024) {
+        if (ok && bsteps > 0) {
             const int stride = kMfHdrBytes + bsteps * 2048;
             std::vector<char> blob((size_t)stride * tabs.size(), 0);
             for (size_t t = 0; t < tabs.size(); t++) {
@@ -2361,7 +2308,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                 rc = upload(ctx, bt, &c->d_bq_mf32);
             }
             if (!rc) {
-                c->mf_ok = true; c->mf_waves = nw; c->mf_halo = H; c->mf_bsteps = bsteps; c->mf_stride = stride;
+                c->mf_ok = true; c->mf_halo = H; c->mf_bsteps = bsteps; c->mf_stride = stride;
                 // wave-stream variant: waves per workgroup that put the most waves on a CU (<= 16: the kernel's <= 128 VGPRs allow
                 // 4 per SIMD) under the 160 KB of LDS; ties go to the smaller workgroup
                 int best = 0;
@@ -2375,16 +2322,15 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                 if (best > 0) rc = dzalloc(ctx, (size_t)c->channels * kBqStateFloats, &c->d_bq_state_alt);
                 if (!rc && iirfold && !iirc.empty()) rc = upload(ctx, iirc, &c->d_mw_iir);
                 c->mfw_ssb_fold = iirfold && c->d_mw_iir; c->mfw_am_fold = amfold && c->d_mw_iir;
-                // only the wave-stream kernel knows the full-rate layout
-                if (fr && (best <= 0 || (cfg->flags & MSDR_CHAIN_MFMA_WG))) c->mf_ok = false;
+                if (best <= 0) c->mf_ok = false;               // not even one wave's window fits next to the fragments: the VALU kernels run
             }
         }
     }
     if (c->mf_fr && !c->mf_ok) { c->mf_fr = false; c->mf_P = 0; }
     // ---- envelope channels with the taps in registers (msdr_chain_amtr.hiph): the exact Fs/4 mixer, both FIRs of every tap set with the
     // same taps (the reference's AM case, Minimal-SDR.ino:917-924), up to 257 taps; rides on the wave-stream kernel's unit table ----
-    if (!rc && f32 && c->mf_ok && c->mfw_nw > 0 && !c->mf_fr && cfg->mixer == MSDR_MIXER_FS4 && !(cfg->flags & (MSDR_CHAIN_MFMA_WG | MSDR_CHAIN_NO_MFMA)) &&
-        at_steps((int)c->ntaps) <= kAtMaxSteps && c->ntaps >= 2 && !getenv("MSDR_NO_AMTR") &&
+    if (!rc && f32 && c->mf_ok && c->mfw_nw > 0 && !c->mf_fr && cfg->mixer == MSDR_MIXER_FS4 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) &&
+        at_steps((int)c->ntaps) <= kAtMaxSteps && c->ntaps >= 2 &&
         // where it wins (profiles/r02/am_matrix.txt: 256 taps with 0 / 1 biquad sections: 7 - 11 % faster than the wave-stream kernel; shorter
         // filters or 2+ sections: equal or slower, the other kernel runs the cascade on the matrix cores).  MSDR_AMTR=1 forces it (tests).
         ((at_steps((int)c->ntaps) == kAtMaxSteps && c->nstages <= 1) || getenv("MSDR_AMTR"))) {
@@ -2429,78 +2375,13 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
             }
         }
     }
-    if (!rc && f32 && !c->d_fset) {       // per-channel table-set index (tap set x {LSB, USB, AM}), shared by the folded and FFT kernels
+    if (!rc && f32 && !c->d_fset) {       // per-channel table-set index (tap set x {LSB, USB, AM}), shared by the folded kernels
         std::vector<int> fs(c->channels);
         for (uint32_t ch = 0; ch < c->channels; ch++) {
             const int m = c->h_mode[ch];
             fs[ch] = c->h_tapset[ch] * 3 + (m == MSDR_MODE_LSB ? 0 : m == MSDR_MODE_USB ? 1 : 2);
         }
         rc = upload(ctx, fs, &c->d_fset);
-    }
-    if (!rc && c->fft_LP) {
-        // H[set*3+v] = FFT_4096(g) * in_scale / 4096,  g[j] = G[N-1-j] (plain convolution order),
-        // G = hI + j hQ (LSB), hI - j hQ (USB), hI (AM; only meaningful when hI == hQ)
-        const int F = kFftF;
-        std::vector<float> Hh((size_t)c->tapsets * 3 * F * 2, 0.0f);
-        std::vector<std::complex<double>> a(F);
-        c->fft_am_ok.assign(c->tapsets, 1);
-        for (uint32_t s = 0; s < c->tapsets; s++) {
-            const float *hi = (const float *)cfg->coeffs_i[s], *hq = (const float *)cfg->coeffs_q[s];
-            for (uint32_t k = 0; k < c->ntaps; k++) if (hi[k] != hq[k]) c->fft_am_ok[s] = 0;
-            for (int v = 0; v < 3; v++) {
-                std::fill(a.begin(), a.end(), std::complex<double>(0, 0));
-                for (uint32_t j = 0; j < c->ntaps; j++) {
-                    const uint32_t k = c->ntaps - 1 - j;
-                    a[j] = (v == 0) ? std::complex<double>(hi[k], hq[k]) : (v == 1) ? std::complex<double>(hi[k], -(double)hq[k])
-                                                                                     : std::complex<double>(hi[k], 0.0);
-                }
-                // iterative radix-2 DIT FFT in double
-                for (int i = 1, j = 0; i < F; i++) {
-                    int bit = F >> 1;
-                    for (; j & bit; bit >>= 1) j ^= bit;
-                    j ^= bit;
-                    if (i < j) std::swap(a[i], a[j]);
-                }
-                for (int len = 2; len <= F; len <<= 1) {
-                    const double ang = -2.0 * 3.14159265358979323846 / len;
-                    for (int i = 0; i < F; i += len)
-                        for (int k = 0; k < len / 2; k++) {
-                            const std::complex<double> w(std::cos(ang * k), std::sin(ang * k));
-                            const std::complex<double> u = a[i + k], t = a[i + k + len / 2] * w;
-                            a[i + k] = u + t; a[i + k + len / 2] = u - t;
-                        }
-                }
-                const double sc = (double)c->in_scale / F;
-                float *dst = Hh.data() + ((size_t)s * 3 + v) * F * 2;
-                for (int k = 0; k < F; k++) { dst[2 * k] = (float)(a[k].real() * sc); dst[2 * k + 1] = (float)(a[k].imag() * sc); }
-            }
-        }
-        rc = upload(ctx, Hh, &c->d_fft_h);
-        if (!rc) {
-            std::vector<float> tw((size_t)(256 + 4096) * 2);
-            for (int m = 0; m < 16; m++)
-                for (int k = 0; k < 16; k++) {
-                    const double ang = -2.0 * 3.14159265358979323846 * k * m / 256.0;
-                    tw[(m * 16 + k) * 2] = (float)std::cos(ang); tw[(m * 16 + k) * 2 + 1] = (float)std::sin(ang);
-                }
-            for (int m = 0; m < 16; m++)
-                for (int k = 0; k < 256; k++) {
-                    const double ang = -2.0 * 3.14159265358979323846 * k * m / 4096.0;
-                    tw[(256 + m * 256 + k) * 2] = (float)std::cos(ang); tw[(256 + m * 256 + k) * 2 + 1] = (float)std::sin(ang);
-                }
-            rc = upload(ctx, tw, &c->d_fft_tw);
-        }
-        if (!rc) {
-            if (c->fft_LP == 15) {
-                std::vector<BiquadCascadeTables<15>> tabs(1);
-                make_cascade_tables<15>(cfg->biquad_coeffs, (int)c->nstages, &tabs[0]);
-                rc = upload(ctx, tabs, (BiquadCascadeTables<15> **)&c->d_bq_fft);
-            } else {
-                std::vector<BiquadCascadeTables<14>> tabs(1);
-                make_cascade_tables<14>(cfg->biquad_coeffs, (int)c->nstages, &tabs[0]);
-                rc = upload(ctx, tabs, (BiquadCascadeTables<14> **)&c->d_bq_fft);
-            }
-        }
     }
     for (uint32_t k = 0; k < c->nnodes && !rc; k++) {
         if (cfg->node_stages[k] < 1 || cfg->node_stages[k] > 4 || !cfg->node_coefs[k]) { rc = fail(MSDR_STATUS_ARGUMENT_ERROR, "biquad node %u misconfigured", k); break; }
@@ -2686,12 +2567,6 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     bool use_fold = f32 && c->fold_P > 0;
     if (use_fold && !c->fold_fs4_exact)
         for (int m : c->h_mode) if (m != MSDR_MODE_LSB && m != MSDR_MODE_USB) { use_fold = false; break; }
-    bool use_fft = f32 && c->fft_LP > 0;
-    if (use_fft)
-        for (uint32_t ch = 0; ch < c->channels; ch++) {
-            const int m = c->h_mode[ch];
-            if (m != MSDR_MODE_LSB && m != MSDR_MODE_USB && !c->fft_am_ok[c->h_tapset[ch]]) { use_fft = false; break; }
-        }
     bool pll_active = false;
     if (c->pll) {
         for (int m : c->h_mode) if (m == MSDR_MODE_SYNCAM) { pll_active = true; break; }
@@ -2707,15 +2582,13 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         }
     }
     const bool use_mf = f32 && c->mf_ok;
-    const bool use_mfw = use_mf && c->mfw_nw > 0 && !(c->flags & MSDR_CHAIN_MFMA_WG);
+    const bool use_mfw = use_mf && c->mfw_nw > 0;
     bool use_qm = !f32 && c->d_qm_tab != nullptr;
     if (use_qm)
         for (int ts : c->h_tapset) if (!c->qm_set_ok[ts]) { use_qm = false; break; }      // a tap >= 32640: the VALU kernel runs
-    if (use_mf) use_fft = false;
-    if (use_fft || use_mf) use_fold = false;
-    const int kTile = use_mfw ? kMwTile : use_mf ? c->mf_waves * kMfWaveTile : use_fft ? kThreads * c->fft_LP : use_fold ? kFoldTile : kChainTile;
-    p.mf_tab = c->d_mf_tab; p.mf_stride = c->mf_stride; p.mf_halo = c->mf_halo; p.mf_bsteps = c->mf_bsteps; p.bq_mf = c->d_bq_mf; p.bq_mf32 = c->d_bq_mf32; p.mf_waves = c->mf_waves;
-    p.fft_h = c->d_fft_h; p.fft_tw = c->d_fft_tw; p.bq_fft = c->d_bq_fft;
+    if (use_mf) use_fold = false;
+    const int kTile = use_mfw ? kMwTile : use_fold ? kFoldTile : kChainTile;
+    p.mf_tab = c->d_mf_tab; p.mf_stride = c->mf_stride; p.mf_halo = c->mf_halo; p.mf_bsteps = c->mf_bsteps; p.bq_mf = c->d_bq_mf; p.bq_mf32 = c->d_bq_mf32;
     const int osc_P = use_mf ? c->mf_P : c->fold_P;            // the matrix-core tables exist for periods up to 32, the VALU fold tables up to 4
     p.ftaps = c->d_ftaps; p.chan_fset = c->d_fset; p.fold_period = osc_P; p.bq_fold = c->d_bq_fold;
     p.fold_rot = osc_P ? (int)(c->phase % osc_P) : 0;
@@ -2818,7 +2691,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
 #endif
     }
 
-    const size_t lds = use_mfw ? mw_lds_bytes(c->mf_halo, c->mf_bsteps, c->mfw_nw, c->mf_fr) : use_mf ? mf_lds_bytes(c->mf_halo, c->mf_bsteps, c->mf_waves) : use_fft ? fft_lds_bytes() : use_fold ? fold_lds_bytes(p.ntaps_pad) : chain_lds_bytes(p.ntaps_pad);
+    const size_t lds = use_mfw ? mw_lds_bytes(c->mf_halo, c->mf_bsteps, c->mfw_nw, c->mf_fr) : use_fold ? fold_lds_bytes(p.ntaps_pad) : chain_lds_bytes(p.ntaps_pad);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && c->events.size() < 8192) {
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -2892,10 +2765,6 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         }
 #endif
     }
-    else if (use_mf && c->mf_waves == 4) { hipLaunchKernelGGL(chain_mfma_kernel<4>, dim3(grid), dim3(256), lds, c->ctx->stream, p); kname = "chain_mfma_kernel<4>"; }
-    else if (use_mf) { block = 512; hipLaunchKernelGGL(chain_mfma_kernel<8>, dim3(grid), dim3(512), lds, c->ctx->stream, p); kname = "chain_mfma_kernel<8>"; }
-    else if (use_fft && c->fft_LP == 15) { hipLaunchKernelGGL((chain_fft_kernel<15>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fft_kernel<15>"; }
-    else if (use_fft) { hipLaunchKernelGGL((chain_fft_kernel<14>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fft_kernel<14>"; }
     else if (use_fold && c->fold_P == 4) { hipLaunchKernelGGL((chain_fold_kernel<4>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<4>"; }
     else if (use_fold && c->fold_P == 2) { hipLaunchKernelGGL((chain_fold_kernel<2>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<2>"; }
     else if (use_fold) { hipLaunchKernelGGL((chain_fold_kernel<1>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<1>"; }
@@ -2967,10 +2836,10 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         if (int rc = msdr_anr_q15(c->anr, c->d_anr_on, c->anr_all, (q15_t *)d_audio, (uint32_t)n_samples)) return rc;
 
     if (c->nnodes == 2) {      // biquad1_dac -> biquad2_dac in one pass over the audio
-        const bool slabs = (c->channels & 63u) == 0 && (n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 && !c->no_biquad_pipe;
+        const bool slabs = (c->channels & 63u) == 0 && (n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0;
         const int per_group = c->nodes[0]->pipe_ch ? c->nodes[0]->pipe_ch : 64;
-        if ((n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 && !c->no_biquad_pipe && c->channels % (unsigned)per_group == 0 &&
-            c->nodes[0]->max_stage == 0 && c->nodes[1]->max_stage == 0 && !c->no_biquad_pipe4) {
+        if ((n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 && c->channels % (unsigned)per_group == 0 &&
+            c->nodes[0]->max_stage == 0 && c->nodes[1]->max_stage == 0) {
             // one stage per node (the reference's configuration): the recursions alone on two waves, the input products element-wise on the others
             if (per_group == 64)
                 hipLaunchKernelGGL((biquad_teensy_pipe4_kernel<2, 64>), dim3(c->channels / 64), dim3(tq4_threads(64)), tq4_lds_bytes(64), c->ctx->stream, (short *)d_audio,

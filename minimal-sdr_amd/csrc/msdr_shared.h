@@ -79,10 +79,6 @@ struct ChainParams {
     int fold_period;           // P: NCO period in samples (1, 2 or 4)
     int fold_rot;              // (absolute index of sample 0 of this call) mod P
     const BiquadCascadeTables<kFoldR> *bq_fold;   // lanes own kFoldR samples
-    // overlap-save FFT kernel (msdr_chain_fft.hiph); chan_fset doubles as the per-channel H-set index
-    const float *fft_h;        // [hsets][4096] complex frequency responses (1/4096 and in_scale folded in)
-    const float *fft_tw;       // complex twiddles: [16][16] W_256^(k m) then [16][256] W_4096^(k m)
-    const void *bq_fft;        // BiquadCascadeTables<LP> for the kernel's LP
     // matrix-core kernel (msdr_chain_mfma.hiph); uses chan_fset, fold_period, fold_rot
     const void *mf_tab;        // [fsets][P rotations] tables: MfmaTableHeader (1 KB) + B fragments, mf_stride bytes apart
     int mf_stride;

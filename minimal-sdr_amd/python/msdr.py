@@ -19,9 +19,7 @@ BQ_LOWPASS, BQ_HIGHPASS, BQ_BANDPASS, BQ_NOTCH, BQ_LOWSHELF, BQ_HIGHSHELF = rang
 AUDIO_SAMPLE_RATE_EXACT = 44117.64706
 MAX_TAPSETS = 8
 CHAIN_NO_TAP_FOLDING = 1
-CHAIN_NO_FFT = 4
 CHAIN_NO_MFMA = 8
-CHAIN_MFMA_WG = 16
 CHAIN_SYNCAM_PLL = 32
 CHAIN_FOLD_ANY_PERIOD = 64
 FE_DCBLOCK, FE_AMP, FE_AGC, FE_ALL = 1, 2, 4, 7

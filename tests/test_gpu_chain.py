@@ -266,13 +266,13 @@ def _q15_nco(p, cycles, length=128):
     return (s / 32768.0).astype(np.float32), (c / 32768.0).astype(np.float32)
 
 
-# folded FIR on the matrix cores (one wave per stream = the default, or workgroup tiles) / on the fp32 VALU
-ENGINES = {"mfw": 0, "mfma": msdr.CHAIN_MFMA_WG, "valu": msdr.CHAIN_NO_MFMA}
-ALL_ENGINES = ["mfw", "mfma", "valu"]
+# folded FIR on the matrix cores (one wave per stream: the default) / on the fp32 VALU (the north-star's formulation)
+ENGINES = {"mfw": 0, "valu": msdr.CHAIN_NO_MFMA}
+ALL_ENGINES = ["mfw", "valu"]
 
 
 def _mf_name(engine, stages, wg_waves=4):
-    return "chain_mfw_kernel<%d>" % stages if engine == "mfw" else "chain_mfma_kernel<%d>" % wg_waves
+    return "chain_mfw_kernel<%d>" % stages
 
 
 @pytest.mark.parametrize("engine", ALL_ENGINES)
@@ -399,12 +399,12 @@ def test_chain_f32_am_with_non_fs4_nco(ctx, orc, engine):
         assert rel_rms(got[c], orc.chain_f32(x[c], m, hi, hq, oi, oq, None)) < TOL
 
 
-# ---------------------------------------------------------------- fp32, overlap-save FFT kernel ---
-@pytest.mark.parametrize("ntaps", [248, 256, 257, 300, 512, 513])
+# ---------------------------------------------------------------- fp32, long FIRs behind a general oscillator table ---
+@pytest.mark.parametrize("ntaps", [248, 257, 513])
 @pytest.mark.parametrize("mode", [orclib.LSB, orclib.USB, orclib.AM])
-def test_chain_f32_fft_kernel_vs_oracle(ctx, orc, ntaps, mode):
-    """Long FIRs take the LDS-resident overlap-save FFT kernel; any oscillator table works there (here one
-    that is NOT short-periodic), AM needs both branches to share their taps."""
+def test_chain_f32_long_fir_behind_a_general_table_vs_oracle(ctx, orc, ntaps, mode):
+    """More than 247 taps behind an oscillator table that is NOT short-periodic: the full-rate matrix-core layout holds up to 247 taps,
+    beyond that the as-written kernel runs (chain_kernel<ArithF32>; round 2's overlap-save FFT kernel for this corner is gone)."""
     rng = np.random.default_rng(ntaps * 3 + mode)
     if mode == orclib.AM:
         hi = (np.sinc(2 * 2800 / 24000 * (np.arange(ntaps) - (ntaps - 1) / 2)) * np.kaiser(ntaps, 7.0)).astype(np.float32)
@@ -419,19 +419,13 @@ def test_chain_f32_fft_kernel_vs_oracle(ctx, orc, ntaps, mode):
     for block in (None, 4999, 128):
         chain.reset()
         got = run_chain(ctx, chain, x, np.float32, block)
-        assert chain.info()["kernel"] == "chain_fft_kernel<%d>" % (15 if ntaps <= 257 else 14), chain.info()
+        assert chain.info()["kernel"] == "chain_kernel<ArithF32>", chain.info()
         for c in range(3):
             want = orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq)
             assert rel_rms(got[c], want) < TOL, (block, c, rel_rms(got[c], want))
-    plain = msdr.Chain(ctx, msdr.ARITH_F32, 3, hi, hq, mixer=msdr.MIXER_NCO, mode=mode, osc_i=oi, osc_q=oq, biquad_coeffs=bq,
-                       flags=msdr.CHAIN_NO_FFT)
-    got2 = run_chain(ctx, plain, x, np.float32)
-    assert not plain.info()["kernel"].startswith("chain_fft")
-    for c in range(3):
-        assert rel_rms(got2[c], orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq)) < TOL
 
 
-def test_chain_f32_fft_am_with_distinct_branches_falls_back(ctx, orc):
+def test_chain_f32_valu_envelope_with_distinct_branches(ctx, orc):
     rng = np.random.default_rng(5)
     hi, hq = _hilbert_pair(256)
     x = rng.integers(-8000, 8001, (2, 6000)).astype(np.int16)
@@ -444,7 +438,7 @@ def test_chain_f32_fft_am_with_distinct_branches_falls_back(ctx, orc):
 
 
 @pytest.mark.parametrize("engine", ALL_ENGINES)
-def test_chain_f32_fft_time_segments_long_stream(ctx, orc, engine):
+def test_chain_f32_time_segments_long_stream(ctx, orc, engine):
     rng = np.random.default_rng(6)
     n = 1 << 20
     x = rng.integers(-8000, 8001, (1, n)).astype(np.int16)
@@ -455,7 +449,7 @@ def test_chain_f32_fft_time_segments_long_stream(ctx, orc, engine):
                        flags=ENGINES[engine])
     got = run_chain(ctx, chain, x, np.float32)
     info = chain.info()
-    assert info["kernel"] == (_mf_name(engine, 2, 8) if engine != "valu" else "chain_fft_kernel<15>") and info["time_segments"] > 1
+    assert info["kernel"] == (_mf_name(engine, 2, 8) if engine != "valu" else "chain_fold_kernel<4>") and info["time_segments"] > 1
     want = orc.chain_f32(x[0], orclib.LSB, hi, hq, oi, oq, bq)
     assert rel_rms(got[0], want) < TOL
 
@@ -463,7 +457,7 @@ def test_chain_f32_fft_time_segments_long_stream(ctx, orc, engine):
 # ---------------------------------------------------------------- fp32, matrix-core kernel ---------
 @pytest.mark.parametrize("ntaps", [1, 2, 31, 33, 64, 100, 129, 256, 512])
 @pytest.mark.parametrize("mode", [orclib.LSB, orclib.AM])
-@pytest.mark.parametrize("engine", ["mfw", "mfma"])
+@pytest.mark.parametrize("engine", ["mfw"])
 def test_chain_f32_mfma_tap_counts(ctx, orc, ntaps, mode, engine):
     """The Toeplitz operand is built per tap count (halo = ntaps - 1 rounded up to 32); Fs/4 mixer, mixed block sizes,
     three channels so that rows of channels > 0 are misaligned for odd n."""
@@ -487,7 +481,7 @@ def test_chain_f32_mfma_tap_counts(ctx, orc, ntaps, mode, engine):
                 assert rel_rms(got[c], want) < TOL, (n, block, c, rel_rms(got[c], want))
 
 
-@pytest.mark.parametrize("engine", ["mfw", "mfma"])
+@pytest.mark.parametrize("engine", ["mfw"])
 def test_chain_f32_mfma_weak_signal_keeps_fp32_accuracy(ctx, orc, engine):
     """The fp16 split of the samples is a FLOATING split (11 significant bits + exact remainder), so a weak signal
     (|x| <= 40) is as accurate as a full-scale one; full-scale extremes (-32768, 32767) are exact too."""

@@ -39,17 +39,25 @@ if line:
         print("algorithmic bytes per launch: %.0f (896 B per transform)" % alg)
 res = {}
 for name in ("fetch", "write"):
-    tot, cnt = 0.0, 0
+    # a step may launch the chain kernel more than once (c5: envelope channels and SSB channels are two instantiations): the figure per
+    # STEP is the sum over the distinct library kernels of their mean per launch
+    per = {}
     for f in glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             kn = r.get("Kernel_Name", "")
             if ("chain_" in kn and "kernel" in kn) or "spectrum_rfft128" in kn or "fir_f32" in kn:
-                tot += float(r.get("Counter_Value", 0)); cnt += 1
-    res[name] = (tot, cnt)
-    print("%s counter: %d chain_kernel dispatches, mean raw value %.1f" % (name.upper() + "_SIZE", cnt, tot / cnt if cnt else float("nan")))
+                a = per.setdefault(kn.split("(")[0], [0.0, 0])
+                a[0] += float(r.get("Counter_Value", 0)); a[1] += 1
+    tot = sum(a[0] / a[1] for a in per.values())
+    cnt = sum(a[1] for a in per.values())
+    res[name] = (tot, cnt, len(per))
+    print("%s counter: %d chain_kernel dispatches of %d kernel(s), sum of the per-launch means %.1f" % (name.upper() + "_SIZE", cnt, len(per), tot))
+    for kn, a in sorted(per.items()):
+        print("    %-90s mean raw value %.1f over %d launches" % (kn[:90], a[0] / a[1], a[1]))
 if res["fetch"][1] and res["write"][1]:
-    fb = res["fetch"][0] / res["fetch"][1] * 1024 * 2      # KiB -> B, gfx950 wide-read correction x2
-    wb = res["write"][0] / res["write"][1] * 1024
-    print("HBM traffic per chain_kernel launch: read %.0f B (FETCH_SIZE x1024 x2), write %.0f B (WRITE_SIZE x1024), total %.0f B" % (fb, wb, fb + wb))
+    fb = res["fetch"][0] * 1024 * 2      # KiB -> B, gfx950 wide-read correction x2
+    wb = res["write"][0] * 1024
+    print("HBM traffic per chain_kernel launch: read %.0f B (FETCH_SIZE x1024 x2), write %.0f B (WRITE_SIZE x1024), total %.0f B%s" % (
+        fb, wb, fb + wb, "   [per STEP: the %d kernels of one step summed]" % res["fetch"][2] if res["fetch"][2] > 1 else ""))
     if line:
         print("traffic / algorithmic = %.3f" % ((fb + wb) / alg))

@@ -188,7 +188,7 @@ int msdr_biquad_df1_f32_destroy(msdr_biquad_df1_f32 *S);
 /* Host only (no device needed): how the library will evaluate this cascade.  *kappa = ||c||_1 ||g||_1 / ||h||_1 (conditioning of
  * the parallel "numerators first" form), *fp32_noise = distance of the sequential fp32 evaluation (arm_biquad_cascade_df1_f32 as
  * written) from a double evaluation on a fixed test signal, *cmsis_order = 1 if instances created with these coefficients run the
- * cascade section by section in CMSIS order instead of the block-parallel solver.  Any output pointer may be NULL. */
+ * cascade section by section in CMSIS order instead of the block-parallel solver (the study: profiles/r02/DESIGN_r02_log.md 4.4c).  Any output pointer may be NULL. */
 int msdr_biquad_df1_f32_cascade_info(uint8_t numStages, const float32_t *pCoeffs, double *kappa, double *fp32_noise, int *cmsis_order);
 
 /* AudioFilterBiquad (src/Audio/filter_biquad.cpp:33-100, filter_biquad.h:33-155): up to 4 stages,

@@ -154,7 +154,7 @@ def test_rfft_init_check_mirrors_arm_rfft_init_q15():
 
 def test_cascade_info_routes_the_reference_cascade_to_the_parallel_solver(orc):
     """msdr_biquad_df1_f32_cascade_info (host only): the reference's LP + notch cascade and the Linkwitz-Riley set stay on the
-    block-parallel IIR, high-pass pairs and narrow low-frequency notches go to CMSIS order (DESIGN.md 4.4c)."""
+    block-parallel IIR, high-pass pairs and narrow low-frequency notches go to CMSIS order (DESIGN.md 4.5)."""
     corr = orclib.AUDIO_SAMPLE_RATE_EXACT / 24000.0
     LP, HP, NT = orclib.BQ_LOWPASS, orclib.BQ_HIGHPASS, orclib.BQ_NOTCH
 

@@ -2310,13 +2310,16 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
             if (!rc) {
                 c->mf_ok = true; c->mf_halo = H; c->mf_bsteps = bsteps; c->mf_stride = stride;
                 // wave-stream variant: waves per workgroup that put the most waves on a CU (<= 16: the kernel's <= 128 VGPRs allow
-                // 4 per SIMD) under the 160 KB of LDS; ties go to the smaller workgroup
-                int best = 0;
+                // 4 per SIMD) under the 160 KB of LDS -- counted in whole waves per SIMD.  A SIMD's tile rate is the same from two waves
+                // on (profiles/r03/c3_trims.txt), so a workgroup is as slow as its fullest SIMD: 13 waves (4 + 3 + 3 + 3) ran 4 % behind
+                // 12 per tile and CU.  Ties go to fewer waves, then to the smaller workgroup.
+                int best = 0, best_eff = 0;
                 for (int w = 1; w <= 16; w++) {
                     const size_t l = mw_lds_bytes(H, bsteps, w, fr);
                     if (l > 160 * 1024) break;
                     const int wgs = std::min<int>((int)((160 * 1024) / l), 16 / w);
-                    if (wgs * w > best) { best = wgs * w; c->mfw_nw = w; }
+                    const int on_cu = wgs * w, eff = on_cu >= 4 ? 4 * (on_cu / 4) : on_cu;
+                    if (eff > best_eff) { best_eff = eff; best = on_cu; c->mfw_nw = w; }
                 }
                 c->mfw_waves_per_cu = best;
                 if (best > 0) rc = dzalloc(ctx, (size_t)c->channels * kBqStateFloats, &c->d_bq_state_alt);

@@ -2313,11 +2313,14 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                 // 4 per SIMD) under the 160 KB of LDS -- counted in whole waves per SIMD.  A SIMD's tile rate is the same from two waves
                 // on (profiles/r03/c3_trims.txt), so a workgroup is as slow as its fullest SIMD: 13 waves (4 + 3 + 3 + 3) ran 4 % behind
                 // 12 per tile and CU.  Ties go to fewer waves, then to the smaller workgroup.
-                int best = 0, best_eff = 0;
-                for (int w = 1; w <= 16; w++) {
+                int best = 0, best_eff = 0, wcap = 16;
+#ifdef MSDR_STAMPS
+                if (const char *e = getenv("MSDR_DBG_NW")) wcap = std::max(1, std::min(16, atoi(e)));    // stamps build: a lone wave per SIMD etc.
+#endif
+                for (int w = 1; w <= wcap; w++) {
                     const size_t l = mw_lds_bytes(H, bsteps, w, fr);
                     if (l > 160 * 1024) break;
-                    const int wgs = std::min<int>((int)((160 * 1024) / l), 16 / w);
+                    const int wgs = std::min<int>((int)((160 * 1024) / l), wcap / w);
                     const int on_cu = wgs * w, eff = on_cu >= 4 ? 4 * (on_cu / 4) : on_cu;
                     if (eff > best_eff) { best_eff = eff; best = on_cu; c->mfw_nw = w; }
                 }

@@ -383,6 +383,26 @@ def test_chain_f32_envelope_taps_in_registers_default_rule_and_mixed_modes(ctx, 
             assert rel_rms(got[0, lo:lo + 64], want[lo:lo + 64]) < TOL, sgi
 
 
+def test_wave_stream_workgroup_is_whole_waves_per_simd(ctx, orc, monkeypatch):
+    """msdr_chain_create sizes the wave-stream kernel's workgroup in whole waves per SIMD: the 40 KB of fragments of a 256-tap envelope
+    table leave LDS for 13 - 16 windows, and 13 waves (4 + 3 + 3 + 3 over the SIMDs) ran 4 % behind 12 per tile (profiles/r03/c3_trims.txt)."""
+    monkeypatch.delenv("MSDR_AMTR", raising=False)
+    rng = np.random.default_rng(321)
+    lp = _lowpass(256)
+    cos4, sin4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+    bq = _f32_biquads(orc, 2)
+    x = rng.integers(-12000, 12001, (8, 5000)).astype(np.int16)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 8, lp, lp, mixer=msdr.MIXER_FS4, mode=orclib.AM, biquad_coeffs=bq)
+    got = run_chain(ctx, chain, x, np.float32, 2048)
+    info = chain.info()
+    assert info["kernel"] == "chain_mfw_kernel<2>"
+    waves = info["block"] // 64
+    on_cu = min(16 // waves, (160 * 1024) // info["lds_bytes"]) * waves
+    assert on_cu >= 8 and on_cu % 4 == 0, info
+    for c in (0, 7):
+        assert rel_rms(got[c], orc.chain_f32(x[c], orclib.AM, lp, lp, sin4, cos4, bq)) < TOL
+
+
 @pytest.mark.parametrize("engine", ALL_ENGINES)
 def test_chain_f32_am_with_non_fs4_nco(ctx, orc, engine):
     """The packed-fp32 folded kernel does AM only for the exact Fs/4 pattern: a q15-rounded fs/4 table (0.99997)

@@ -2337,8 +2337,9 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
     // same taps (the reference's AM case, Minimal-SDR.ino:917-924), up to 257 taps; rides on the wave-stream kernel's unit table ----
     if (!rc && f32 && c->mf_ok && c->mfw_nw > 0 && !c->mf_fr && cfg->mixer == MSDR_MIXER_FS4 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) &&
         at_steps((int)c->ntaps) <= kAtMaxSteps && c->ntaps >= 2 &&
-        // where it wins (profiles/r02/am_matrix.txt: 256 taps with 0 / 1 biquad sections: 7 - 11 % faster than the wave-stream kernel; shorter
-        // filters or 2+ sections: equal or slower, the other kernel runs the cascade on the matrix cores).  MSDR_AMTR=1 forces it (tests).
+        // where it wins (256 taps with 0 / 1 biquad sections: 7 - 11 % faster than the wave-stream kernel in round 2, profiles/r02/am_matrix.txt;
+        // 2 - 4 % after round 3's work on the other kernel, profiles/r03/c3_trims.txt; shorter filters or 2+ sections: equal or slower, the other
+        // kernel runs the cascade on the matrix cores).  MSDR_AMTR=1 forces it (tests).
         ((at_steps((int)c->ntaps) == kAtMaxSteps && c->nstages <= 1) || getenv("MSDR_AMTR"))) {
         bool same = true;
         for (uint32_t s2 = 0; s2 < c->tapsets && same; s2++)

@@ -2313,7 +2313,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                 // 4 per SIMD) under the 160 KB of LDS -- counted in whole waves per SIMD.  A SIMD's tile rate is the same from two waves
                 // on (profiles/r03/c3_trims.txt), so a workgroup is as slow as its fullest SIMD: 13 waves (4 + 3 + 3 + 3) ran 4 % behind
                 // 12 per tile and CU.  Ties go to fewer waves, then to the smaller workgroup.
-                int best = 0, best_eff = 0, wcap = (MSDR_MW_RESIDENT && c->nstages == 2) ? 12 : 16;
+                int best = 0, best_eff = 0, wcap = 16;
 #ifdef MSDR_STAMPS
                 if (const char *e = getenv("MSDR_DBG_NW")) wcap = std::max(1, std::min(16, atoi(e)));    // stamps build: a lone wave per SIMD etc.
 #endif

@@ -2095,12 +2095,12 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                 matmul(Pw, Pw, Pw);
             }
             memcpy(Pw, Mt, sizeof Pw);
-            for (int l = 0; l < 32; l++) {                          // M^(l+1): pair-major [pair][lane] float2, pairs = the column halves the scan uses
+            for (int l = 0; l < 32; l++) {                          // M^(l+1): lane-major [lane][pair] float2, pairs = the column halves the scan uses
                 const int pidx2[6] = {0, 2, 4, 6, 10, 14}, pidx1[2] = {0, 4};      // first float of each pair in the column-major 4x4
                 const int npairs = (S_ == 2) ? 6 : 2;
                 for (int q = 0; q < npairs; q++) {
                     const int f = (S_ == 2) ? pidx2[q] : pidx1[q];
-                    for (int e = 0; e < 2; e++) iirc[kMwIirLane + (q * 32 + l) * 2 + e] = (float)Pw[(f + e) & 3][(f + e) >> 2];
+                    for (int e = 0; e < 2; e++) iirc[kMwIirLane + (l * npairs + q) * 2 + e] = (float)Pw[(f + e) & 3][(f + e) >> 2];
                 }
                 matmul(Pw, Mt, Pw);
             }

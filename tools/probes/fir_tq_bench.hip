@@ -25,6 +25,7 @@ __global__ void fill_kernel(float *x, size_t n, unsigned seed)
     }
 }
 
+static double g_seconds = 0.0;       // > 0: loop the variant for that long (power / clock sampling from outside), then report
 template <int ABL>
 static double run(const char *name, TqParams q, unsigned grid, size_t lds, unsigned *d_ctr, int fronts)
 {
@@ -34,7 +35,8 @@ static double run(const char *name, TqParams q, unsigned grid, size_t lds, unsig
     std::vector<float> t;
     int flip = 0;
     CHECK(hipMemset(d_ctr, 0, 2 * kTqMaxFronts * kTqCtrStride * 4));
-    for (int r = 0; r < 60; r++) {
+    const int reps = g_seconds > 0 ? (int)(g_seconds / 1.5e-3) : 60;
+    for (int r = 0; r < reps; r++) {
         q.ctr = d_ctr + (size_t)flip * kTqMaxFronts * kTqCtrStride; q.ctr_next = d_ctr + (size_t)(flip ^ 1) * kTqMaxFronts * kTqCtrStride;
         flip ^= 1;
         CHECK(hipEventRecord(e0));
@@ -42,7 +44,7 @@ static double run(const char *name, TqParams q, unsigned grid, size_t lds, unsig
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-        if (r >= 20) t.push_back(ms);
+        if (r >= 20 && t.size() < 4096) t.push_back(ms);
     }
     CHECK(hipGetLastError());
     std::sort(t.begin(), t.end());
@@ -58,6 +60,8 @@ int main(int argc, char **argv)
     const int channels = 4096, N = 256;
     const long long n = 1LL << 18;
     const int fronts = argc > 1 ? atoi(argv[1]) : 32;
+    const int only = argc > 2 ? atoi(argv[2]) : -1;            // one variant (its ABL bits) ...
+    g_seconds = argc > 3 ? atof(argv[3]) : 0.0;                // ... looped for this many seconds
     float *x, *y, *hist; char *tab; unsigned *ctr;
     CHECK(hipMalloc(&x, (size_t)channels * n * 4)); CHECK(hipMalloc(&y, (size_t)channels * n * 4));
     const int hist_len = 255;
@@ -91,8 +95,24 @@ int main(int argc, char **argv)
     const unsigned grid = 512;
     const size_t lds = 4 * tr_wave_bytes(trs);
     CHECK(hipDeviceSynchronize());
+    if (only >= 0) {
+        switch (only) {
+        case 0: run<0>("product", q, grid, lds, ctr, fronts); break;
+        case 1: run<1>("no matrix instructions", q, grid, lds, ctr, fronts); break;
+        case 2: run<2>("no global loads / stores in the steady state", q, grid, lds, ctr, fronts); break;
+        case 3: run<3>("neither", q, grid, lds, ctr, fronts); break;
+        case 8: run<8>("30 of 36 product triples (fast-FIR product count)", q, grid, lds, ctr, fronts); break;
+        case 24: run<24>("30 of 36 product triples + the split's side work (fast-FIR upper bound)", q, grid, lds, ctr, fronts); break;
+        case 10: run<10>("30 of 36 product triples, no global traffic", q, grid, lds, ctr, fronts); break;
+        default: printf("variant %d not built\n", only); return 1;
+        }
+        return 0;
+    }
     for (int rep = 0; rep < 2; rep++) {
         run<0>("product", q, grid, lds, ctr, fronts);
+        run<8>("30 of 36 product triples (fast-FIR product count)", q, grid, lds, ctr, fronts);
+        run<24>("30 of 36 product triples + the split's side work (fast-FIR upper bound)", q, grid, lds, ctr, fronts);
+        run<10>("30 of 36 product triples, no global traffic", q, grid, lds, ctr, fronts);
         run<1>("no matrix instructions", q, grid, lds, ctr, fronts);
         run<2>("no global loads / stores in the steady state", q, grid, lds, ctr, fronts);
         run<3>("neither", q, grid, lds, ctr, fronts);

@@ -156,6 +156,10 @@ typedef struct msdr_fir_q15 msdr_fir_q15;
 int msdr_fir_q15_create(msdr_ctx *ctx, uint16_t numTaps, const q15_t *pCoeffs, uint32_t channels, msdr_fir_q15 **out);
 int msdr_fir_q15_process(msdr_fir_q15 *S, const q15_t *d_src, q15_t *d_dst, uint32_t blockSize);
 int msdr_fir_q15_reset(msdr_fir_q15 *S);
+/* New coefficients for a running filter, state kept: what rewriting the caller-owned array behind S->pCoeffs does in the reference
+ * (the instance only holds the pointer, arm_fir_init_q15.c:100-109; the bandwidth menu rewrites FIR_AM_coeffs in place with no
+ * init_FIR(), UI.cpp:337-345, Minimal-SDR.ino:221-223).  Same numTaps as at creation.  Stream-ordered behind the calls queued so far. */
+int msdr_fir_q15_set_coeffs(msdr_fir_q15 *S, const q15_t *pCoeffs);
 int msdr_fir_q15_destroy(msdr_fir_q15 *S);
 
 /* arm_fir_init_f32 / arm_fir_f32 (prototypes arm_math.h:1182-1202; CMSIS-DSP V1.5.x). Any numTaps >= 1. */
@@ -163,6 +167,7 @@ typedef struct msdr_fir_f32 msdr_fir_f32;
 int msdr_fir_f32_create(msdr_ctx *ctx, uint16_t numTaps, const float32_t *pCoeffs, uint32_t channels, msdr_fir_f32 **out);
 int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, float32_t *d_dst, uint32_t blockSize);
 int msdr_fir_f32_reset(msdr_fir_f32 *S);
+int msdr_fir_f32_set_coeffs(msdr_fir_f32 *S, const float32_t *pCoeffs);   /* as msdr_fir_q15_set_coeffs: state kept, same numTaps */
 const char *msdr_fir_f32_kernel_name(msdr_fir_f32 *S);      /* the kernel msdr_fir_f32_process launches for this instance */
 /* Filters of 16..513 taps run on the matrix cores with the samples as two fp16 pieces (22 bits) after a power-of-two scale.  By
  * default the scale is chosen per 1024-output tile from the data (block floating point): nothing to declare.  max_abs > 0 pins
@@ -184,12 +189,28 @@ typedef struct msdr_biquad_df1_f32 msdr_biquad_df1_f32;
 int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, const float32_t *pCoeffs, uint32_t channels, msdr_biquad_df1_f32 **out);
 int msdr_biquad_df1_f32_process(msdr_biquad_df1_f32 *S, const float32_t *d_src, float32_t *d_dst, uint32_t blockSize);
 int msdr_biquad_df1_f32_reset(msdr_biquad_df1_f32 *S);
+/* New coefficients (all 5 * numStages of them) for a running cascade with CMSIS semantics: the filter carries on from the state
+ * arm_biquad_cascade_df1_f32 would hold in pState -- x[n-1], x[n-2], y[n-1], y[n-2] of every stage (arm_math.h:1233) -- as it does
+ * when a caller rewrites pCoeffs between two calls.  The block-parallel kernels keep their state in another basis (numerator history
+ * + all-pole section states), which depends on the coefficients: the library converts old basis -> CMSIS state -> new basis on the
+ * host (csrc/msdr_cascade_state.h), per channel, and switches between the block-parallel and the CMSIS-order kernel if the new
+ * cascade's conditioning asks for it (msdr_biquad_df1_f32_cascade_info).  Synchronises the stream.  ARGUMENT_ERROR if the old
+ * cascade's state cannot be expressed as a CMSIS state (a later stage's numerator shares a root with an earlier stage's denominator). */
+int msdr_biquad_df1_f32_set_coeffs(msdr_biquad_df1_f32 *S, const float32_t *pCoeffs);
+/* The state as CMSIS keeps it: pState[4 * numStages] of one channel (synchronises the stream). */
+int msdr_biquad_df1_f32_get_cmsis_state(msdr_biquad_df1_f32 *S, uint32_t channel, float32_t *pState);
 int msdr_biquad_df1_f32_destroy(msdr_biquad_df1_f32 *S);
 /* Host only (no device needed): how the library will evaluate this cascade.  *kappa = ||c||_1 ||g||_1 / ||h||_1 (conditioning of
  * the parallel "numerators first" form), *fp32_noise = distance of the sequential fp32 evaluation (arm_biquad_cascade_df1_f32 as
  * written) from a double evaluation on a fixed test signal, *cmsis_order = 1 if instances created with these coefficients run the
  * cascade section by section in CMSIS order instead of the block-parallel solver (the study: profiles/r02/DESIGN_r02_log.md 4.4c).  Any output pointer may be NULL. */
 int msdr_biquad_df1_f32_cascade_info(uint8_t numStages, const float32_t *pCoeffs, double *kappa, double *fp32_noise, int *cmsis_order);
+/* Host only: the two state conventions of one cascade (see msdr_biquad_df1_f32_set_coeffs).  lib_state[16]: [0..7] = the cascade's
+ * last inputs d[n-1-k] (2 * numStages used), [8 + 2 s], [9 + 2 s] = w[n-1], w[n-2] of all-pole section s.  pState: CMSIS, 4 per stage.
+ * from_cmsis keeps lib_state[0..7] as given on entry (the input history; entries 0, 1 must equal pState[0], pState[1]) and fills
+ * [8..15] so that the block-parallel form continues exactly as arm_biquad_cascade_df1_f32 would from pState. */
+int msdr_biquad_df1_f32_state_to_cmsis(uint8_t numStages, const float32_t *pCoeffs, const float32_t lib_state[16], float32_t *pState);
+int msdr_biquad_df1_f32_state_from_cmsis(uint8_t numStages, const float32_t *pCoeffs, const float32_t *pState, float32_t lib_state[16]);
 
 /* AudioFilterBiquad (src/Audio/filter_biquad.cpp:33-100, filter_biquad.h:33-155): up to 4 stages,
  * Q2.30 coefficients, int16 data, 14-bit error feedback.  A new node passes nothing (all-zero
@@ -379,6 +400,28 @@ int msdr_chain_init_fir(msdr_chain *chain);
  * The Teensy biquad NODES of a Q15 chain keep their history (the reference never clears it, filter_biquad.cpp:95-97). */
 int msdr_chain_reset(msdr_chain *chain);
 int msdr_chain_set_mode(msdr_chain *chain, uint32_t channel, int32_t mode, int32_t tapset);
+/* ---- live updates: what the reference changes while the stream runs, every filter state kept ----------------------------------
+ * All four synchronise the context's stream, rebuild the device tables of the chain on the host and take effect with the next
+ * msdr_chain_process(); FIR history, cascade / node state, PLL and LMS state and the mixer's table position are untouched.
+ *
+ * msdr_chain_set_taps: new coefficients for one tap set (q15_t[num_taps] or float32_t[num_taps] by arith, CMSIS order) -- the
+ *   bandwidth menu rewriting FIR_AM_coeffs in place under the running arm_fir_fast_q15 (UI.cpp:337-345, Minimal-SDR.ino:221-223:
+ *   no init_FIR(), the instance holds a pointer, arm_fir_init_q15.c:100-109).  Every channel on that tap set hears the new filter
+ *   from its next sample on, over the old filter's history.  F32 chains whose SSB tables carry the cascade's numerator hand the
+ *   true numerator history over as first-sample corrections, as msdr_chain_set_mode does.
+ * msdr_chain_set_node_coefficients (Q15): AudioFilterBiquad::setCoefficients(stage, coef) on biquad node `node` (0 = biquad1_dac,
+ *   1 = biquad2_dac) of a running chain -- tune() re-programming the notch on every retune, Minimal-SDR.ino:356 ->
+ *   filter_biquad.cpp:84-100; history kept (:95-97), stage >= 4 silently ignored (:86).
+ * msdr_chain_set_biquad_coeffs (F32): all 5 * num_biquad_stages coefficients of the arm_biquad_cascade_df1_f32 stage, CMSIS
+ *   semantics (the filter carries on from the pState arm_biquad_cascade_df1_f32 would hold; see msdr_biquad_df1_f32_set_coeffs).
+ *   The number of stages is fixed at creation, as numStages is in CMSIS.
+ * msdr_chain_set_osc: new contents for the NCO tables (same osc_len) -- AudioEffectFreqConv reads the global Osc_I_buffer_i /
+ *   Osc_Q_buffer_i on every update() (freq_conv.h:33-34, freq_conv.cpp:70-103), so a sketch that rewrites them retunes the mixer
+ *   without touching anything else; the position in the table carries on. */
+int msdr_chain_set_taps(msdr_chain *chain, uint32_t tapset, const void *coeffs_i, const void *coeffs_q);
+int msdr_chain_set_node_coefficients(msdr_chain *chain, uint32_t node, uint32_t stage, const int32_t coef[5]);
+int msdr_chain_set_biquad_coeffs(msdr_chain *chain, const float32_t *biquad_coeffs);
+int msdr_chain_set_osc(msdr_chain *chain, const void *osc_i, const void *osc_q);
 /* ANR_on per channel (host array of `channels` values, or NULL: anr_on_all for every channel); the LMS filter then runs between
  * the demodulator and the biquad nodes / cascade (Minimal-SDR.ino:702-770).  Its state is created on first use and cleared by
  * msdr_chain_reset() (not by msdr_chain_init_fir()).  Q15 chains: as the reference, on the int16 audio.  F32 chains (an

@@ -10,9 +10,13 @@
  *   * msdr_cmsis_bind(ctx, channels) once: the CMSIS signatures carry neither a device nor a batch width.  Every call then works
  *     on a BLOCK BATCH -- pSrc / pDst are DEVICE pointers to [channels][blockSize] samples (msdr_malloc), one filter state per
  *     channel kept by the library in HBM.  channels = 1 is the reference's shape.
- *   * the instance struct is the reference's (same fields); the caller-owned pCoeffs are read at *_init time (re-run the init
- *     after changing them, as init_FIR() does on every retune, Minimal-SDR.ino:901-930); the caller-owned pState is cleared as the
- *     reference's init does and is otherwise unused (the state lives on the device).
+ *   * the instance struct is the reference's (same fields).  The caller-owned pCoeffs stay the caller's, as in CMSIS (the instance
+ *     holds the pointer, arm_fir_init_q15.c:100-109): every process call compares the array with the bytes its device tables were
+ *     built from and, if the caller has rewritten it in place -- the bandwidth menu does, with no init_FIR(), UI.cpp:337-345 +
+ *     Minimal-SDR.ino:221-223 -- rebuilds the tables and carries on with the filter state kept (numTaps host compares per call; the
+ *     biquad cascade keeps arm_biquad_cascade_df1_f32's pState semantics across the change, msdr_biquad_df1_f32_set_coeffs).  A
+ *     re-run of the init zeroes the state, as init_FIR() does on every retune (Minimal-SDR.ino:901-930).  The caller-owned pState
+ *     is cleared as the reference's init does and is otherwise unused (the state lives on the device).
  *   * errors: the init keeps arm_fir_init_q15's contract (odd numTaps -> ARM_MATH_ARGUMENT_ERROR, instance left untouched,
  *     arm_fir_init_q15.c:93-96); the void process functions cannot report anything -- msdr_last_error() has the text.
  * Define MSDR_CMSIS_NAMES before including this header to get the arm_* names themselves as macros. */

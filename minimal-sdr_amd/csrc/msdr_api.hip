@@ -17,6 +17,7 @@
 #include "msdr_fir_f32tq.hiph"
 #include "msdr_chain_amtr.hiph"
 #include "msdr_design.h"
+#include "msdr_cascade_state.h"
 
 #include <algorithm>
 #include <cmath>
@@ -823,6 +824,28 @@ extern "C" int msdr_fir_q15_destroy(msdr_fir_q15 *S)
     if (S) { hipFree(S->d_qm_tab); hipFree(S->d_qm_order); }
     return fir_destroy(S);
 }
+// New coefficients under a running filter (the reference: the array behind S->pCoeffs rewritten in place, UI.cpp:337-345 +
+// Minimal-SDR.ino:221-223; arm_fir_init_q15.c:100-109 stored the pointer only).  Every device table is rebuilt the way create builds
+// it -- by creating a second instance -- and the running instance's state (its history pair) moves over; the old tables go once the
+// work queued on them has finished.
+template <typename Inst, typename Create>
+static int fir_swap_coeffs(Inst *S, Create &&create)
+{
+    Inst *n = nullptr;
+    if (int rc = create(&n)) return rc;
+    if (n->hist_len != S->hist_len || n->channels != S->channels) { (void)fir_destroy(n); return fail(MSDR_STATUS_SIZE_MISMATCH, "internal: geometry changed"); }
+    std::swap(n->d_hist[0], S->d_hist[0]); std::swap(n->d_hist[1], S->d_hist[1]); n->cur = S->cur;
+    std::swap(*S, *n);
+    return 0;                                   // the caller destroys n (the old tables + the fresh, unused history)
+}
+extern "C" int msdr_fir_q15_set_coeffs(msdr_fir_q15 *S, const q15_t *pCoeffs)
+{
+    if (!S || !pCoeffs) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    msdr_fir_q15 *old = nullptr;
+    auto create = [&](msdr_fir_q15 **n) { const int rc = msdr_fir_q15_create(S->ctx, (uint16_t)S->ntaps, pCoeffs, S->channels, n); old = *n; return rc; };
+    if (int rc = fir_swap_coeffs(S, create)) { if (old) msdr_fir_q15_destroy(old); return rc; }
+    return msdr_fir_q15_destroy(old);
+}
 
 extern "C" int msdr_fir_f32_destroy(msdr_fir_f32 *S);
 static int fir_f32_upload_header(msdr_fir_f32 *S)
@@ -970,6 +993,20 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
     return 0;
 }
 extern "C" int msdr_fir_f32_reset(msdr_fir_f32 *S) { return fir_reset(S); }
+extern "C" int msdr_fir_f32_set_coeffs(msdr_fir_f32 *S, const float32_t *pCoeffs)
+{
+    if (!S || !pCoeffs) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    msdr_fir_f32 *old = nullptr;
+    const float range = S->input_range;
+    auto create = [&](msdr_fir_f32 **n) {
+        int rc = msdr_fir_f32_create(S->ctx, (uint16_t)S->ntaps, pCoeffs, S->channels, n);
+        old = *n;
+        if (!rc && range > 0.0f) rc = msdr_fir_f32_set_input_range(*n, range);
+        return rc;
+    };
+    if (int rc = fir_swap_coeffs(S, create)) { if (old) msdr_fir_f32_destroy(old); return rc; }
+    return msdr_fir_f32_destroy(old);
+}
 // which kernel msdr_fir_f32_process launches for this instance (benchmarks / tests)
 extern "C" const char *msdr_fir_f32_kernel_name(msdr_fir_f32 *S)
 {
@@ -1000,6 +1037,7 @@ struct msdr_biquad_df1_f32 {
     float *d_coeffs;      // sequential: the 5 x stages coefficients
     float *d_seq_scratch; // sequential, few channels x long block: the segments' warm-up samples (biquad_seqseg_gather_kernel)
     size_t seq_scratch_floats;
+    std::vector<float> h_coeffs;      // 5 x stages, as given (msdr_biquad_df1_f32_set_coeffs converts the state between the two cascades)
 };
 
 extern "C" int msdr_biquad_df1_f32_cascade_info(uint8_t numStages, const float32_t *pCoeffs, double *kappa, double *fp32_noise, int *cmsis_order)
@@ -1026,6 +1064,7 @@ extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, cons
     S->d_coeffs = nullptr; S->d_seq_scratch = nullptr; S->seq_scratch_floats = 0;
     S->sequential = numStages > 0 && cascade_needs_cmsis_order(pCoeffs, (int)numStages);
     S->seq_segments = true;
+    if (numStages) S->h_coeffs.assign(pCoeffs, pCoeffs + 5 * numStages);
     if (S->sequential) {
         std::vector<float> cf(pCoeffs, pCoeffs + 5 * numStages);
         if (int rc = upload(ctx, cf, &S->d_coeffs)) { delete S; return rc; }
@@ -1117,6 +1156,102 @@ extern "C" int msdr_biquad_df1_f32_destroy(msdr_biquad_df1_f32 *S)
     hipFree(S->d_tabs); hipFree(S->d_state); hipFree(S->d_state_alt); hipFree(S->d_coeffs); hipFree(S->d_seq_scratch);
     delete S;
     return 0;
+}
+
+// ---- the cascade's state in CMSIS terms (msdr_cascade_state.h) ----
+extern "C" int msdr_biquad_df1_f32_state_to_cmsis(uint8_t numStages, const float32_t *pCoeffs, const float32_t lib_state[16], float32_t *pState)
+{
+    if (numStages > kMaxStages || (numStages && !pCoeffs) || !lib_state || !pState) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad argument");
+    cstate::Bridge br;
+    br.build(pCoeffs, pCoeffs, (int)numStages);
+    if (!br.ok_to) return fail(MSDR_STATUS_ARGUMENT_ERROR, "this cascade's block-parallel state has no unique CMSIS state (a numerator shares a root with an earlier denominator)");
+    double D[8], Y[2 * kMaxStages + 2];
+    for (int k = 0; k < 8; k++) D[k] = lib_state[k];
+    br.lib_to_cmsis(D, lib_state, Y);
+    cstate::Bridge::y_to_pstate(Y, (int)numStages, pState);
+    return 0;
+}
+extern "C" int msdr_biquad_df1_f32_state_from_cmsis(uint8_t numStages, const float32_t *pCoeffs, const float32_t *pState, float32_t lib_state[16])
+{
+    if (numStages > kMaxStages || (numStages && !pCoeffs) || !lib_state || !pState) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad argument");
+    cstate::Bridge br;
+    br.build(pCoeffs, pCoeffs, (int)numStages);
+    if (!br.ok_from) return fail(MSDR_STATUS_ARGUMENT_ERROR, "no block-parallel state reproduces this CMSIS state");
+    double D[8], Y[2 * kMaxStages + 2];
+    cstate::Bridge::pstate_to_y(pState, (int)numStages, Y);
+    for (int k = 0; k < 8; k++) D[k] = (k < 2 * numStages) ? lib_state[k] : 0.0;
+    if (numStages) { D[0] = Y[0]; D[1] = Y[1]; }
+    for (int k = 0; k < 8; k++) lib_state[k] = (float)D[k];
+    for (int k = 8; k < 16; k++) lib_state[k] = 0.0f;
+    br.cmsis_to_lib(Y, D, lib_state + 8);
+    return 0;
+}
+// every channel's state of a stage instance as CMSIS values Y (2 S + 2 per channel) and input history D (8 per channel)
+static int biquad_df1_read_cmsis(msdr_biquad_df1_f32 *S, const cstate::Bridge &br, std::vector<double> &Y, std::vector<double> &D)
+{
+    const int St = (int)S->stages, ny = 2 * St + 2;
+    std::vector<float> st((size_t)S->channels * kBqStateFloats);
+    HIP_TRY(hipStreamSynchronize(S->ctx->stream));
+    HIP_TRY(hipMemcpy(st.data(), S->d_state, st.size() * sizeof(float), hipMemcpyDeviceToHost));
+    Y.assign((size_t)S->channels * ny, 0.0); D.assign((size_t)S->channels * 8, 0.0);
+    for (uint32_t ch = 0; ch < S->channels; ch++) {
+        const float *r = st.data() + (size_t)ch * kBqStateFloats;
+        double *y = Y.data() + (size_t)ch * ny, *d = D.data() + (size_t)ch * 8;
+        if (S->sequential) {
+            cstate::Bridge::pstate_to_y(r, St, y);
+            d[0] = y[0]; d[1] = y[1];                              // (older inputs are not part of a CMSIS state: zeros, a valid choice)
+        } else {
+            for (int k = 0; k < 8; k++) d[k] = r[k];
+            br.lib_to_cmsis(d, r, y);
+        }
+    }
+    return 0;
+}
+static int biquad_df1_write_cmsis(msdr_biquad_df1_f32 *S, const cstate::Bridge &br, const std::vector<double> &Y, const std::vector<double> &D)
+{
+    const int St = (int)S->stages, ny = 2 * St + 2;
+    std::vector<float> st((size_t)S->channels * kBqStateFloats, 0.0f);
+    for (uint32_t ch = 0; ch < S->channels; ch++) {
+        float *r = st.data() + (size_t)ch * kBqStateFloats;
+        const double *y = Y.data() + (size_t)ch * ny, *d = D.data() + (size_t)ch * 8;
+        if (S->sequential) cstate::Bridge::y_to_pstate(y, St, r);
+        else {
+            for (int k = 0; k < 2 * St; k++) r[k] = (float)d[k];
+            br.cmsis_to_lib(y, d, r + 8);
+        }
+    }
+    HIP_TRY(hipMemcpy(S->d_state, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int msdr_biquad_df1_f32_get_cmsis_state(msdr_biquad_df1_f32 *S, uint32_t channel, float32_t *pState)
+{
+    if (!S || !pState || channel >= S->channels) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad argument");
+    if (int rc = bind(S->ctx)) return rc;
+    if (S->stages == 0) return 0;
+    float r[kBqStateFloats];
+    HIP_TRY(hipStreamSynchronize(S->ctx->stream));
+    HIP_TRY(hipMemcpy(r, S->d_state + (size_t)channel * kBqStateFloats, sizeof r, hipMemcpyDeviceToHost));
+    if (S->sequential) { memcpy(pState, r, (size_t)4 * S->stages * sizeof(float)); return 0; }
+    return msdr_biquad_df1_f32_state_to_cmsis((uint8_t)S->stages, S->h_coeffs.data(), r, pState);
+}
+extern "C" int msdr_biquad_df1_f32_set_coeffs(msdr_biquad_df1_f32 *S, const float32_t *pCoeffs)
+{
+    if (!S || (S->stages && !pCoeffs)) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    if (int rc = bind(S->ctx)) return rc;
+    if (S->stages == 0) return 0;
+    cstate::Bridge br;
+    br.build(S->h_coeffs.data(), pCoeffs, (int)S->stages);
+    if (!S->sequential && !br.ok_to)
+        return fail(MSDR_STATUS_ARGUMENT_ERROR, "the running cascade's block-parallel state has no unique CMSIS state (a numerator shares a root with an earlier denominator)");
+    std::vector<double> Y, D;
+    if (int rc = biquad_df1_read_cmsis(S, br, Y, D)) return rc;
+    msdr_biquad_df1_f32 *n = nullptr;
+    if (int rc = msdr_biquad_df1_f32_create(S->ctx, (uint8_t)S->stages, pCoeffs, S->channels, &n)) return rc;
+    if (!n->sequential && !br.ok_from) { msdr_biquad_df1_f32_destroy(n); return fail(MSDR_STATUS_ARGUMENT_ERROR, "no block-parallel state reproduces the CMSIS state under the new coefficients"); }
+    n->seq_segments = S->seq_segments;
+    if (int rc = biquad_df1_write_cmsis(n, br, Y, D)) { msdr_biquad_df1_f32_destroy(n); return rc; }
+    std::swap(*S, *n);
+    return msdr_biquad_df1_f32_destroy(n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1638,8 +1773,57 @@ extern "C" int msdr_spectrum_destroy(msdr_spectrum *S)
 // ------------------------------------------------------------------------------------------------
 // fused chain
 // ------------------------------------------------------------------------------------------------
+// A deep host copy of the configuration a chain was created from: the live updates (msdr_chain_set_taps / set_osc /
+// set_biquad_coeffs) edit it and rebuild the chain's device tables through msdr_chain_create itself -- one table builder, not two.
+struct ChainCfgStore {
+    msdr_chain_config cfg;                            // scalars; the pointers inside are not valid, view() fills them in
+    std::vector<char> ci[MSDR_MAX_TAPSETS], cq[MSDR_MAX_TAPSETS], osc_i, osc_q;
+    std::vector<float> bq;
+    std::vector<int32_t> node[2];
+    void capture(const msdr_chain_config *c)
+    {
+        cfg = *c;
+        const size_t el = (c->arith == MSDR_ARITH_F32) ? sizeof(float) : sizeof(int16_t);
+        for (uint32_t s = 0; s < c->num_tapsets && s < MSDR_MAX_TAPSETS; s++) {
+            ci[s].assign((const char *)c->coeffs_i[s], (const char *)c->coeffs_i[s] + el * c->num_taps);
+            cq[s].assign((const char *)c->coeffs_q[s], (const char *)c->coeffs_q[s] + el * c->num_taps);
+        }
+        osc_i.clear(); osc_q.clear();
+        if (c->mixer == MSDR_MIXER_NCO && c->osc_i && c->osc_q) {
+            osc_i.assign((const char *)c->osc_i, (const char *)c->osc_i + el * c->osc_len);
+            osc_q.assign((const char *)c->osc_q, (const char *)c->osc_q + el * c->osc_len);
+        }
+        bq.clear();
+        if (c->arith == MSDR_ARITH_F32 && c->num_biquad_stages && c->biquad_coeffs) bq.assign(c->biquad_coeffs, c->biquad_coeffs + 5 * c->num_biquad_stages);
+        for (int k = 0; k < 2; k++) {
+            node[k].clear();
+            if (c->arith == MSDR_ARITH_Q15 && (uint32_t)k < c->num_biquad_nodes && c->node_coefs[k]) node[k].assign(c->node_coefs[k], c->node_coefs[k] + 5 * c->node_stages[k]);
+        }
+    }
+    void view(msdr_chain_config *out, const std::vector<int> &mode, const std::vector<int> &tapset) const
+    {
+        *out = cfg;
+        for (uint32_t s = 0; s < MSDR_MAX_TAPSETS; s++) {
+            out->coeffs_i[s] = (s < cfg.num_tapsets) ? (const void *)ci[s].data() : nullptr;
+            out->coeffs_q[s] = (s < cfg.num_tapsets) ? (const void *)cq[s].data() : nullptr;
+        }
+        out->osc_i = osc_i.empty() ? nullptr : (const void *)osc_i.data();
+        out->osc_q = osc_q.empty() ? nullptr : (const void *)osc_q.data();
+        out->biquad_coeffs = bq.empty() ? nullptr : bq.data();
+        for (int k = 0; k < 2; k++) out->node_coefs[k] = node[k].empty() ? nullptr : node[k].data();
+        out->mode = mode.data(); out->tapset = tapset.data();
+    }
+};
+
 struct msdr_chain {
     msdr_ctx *ctx;
+    ChainCfgStore store;
+    double own_d_bound, own_sig_bound;   // what this chain's own tap sets can leave in the cascade's state (floors for a rebuilt chain's table scales)
+    // msdr_chain_set_osc: the tables that were in force when the samples still in the FIR history arrived, oldest first.  While any is
+    // pending the chain runs chain_kernel<Arith>, which mixes every history sample with the table of its own time.
+    struct OscPending { void *d_tab; long long elapsed; };
+    std::vector<OscPending> osc_pending;
+    bool force_generic = false;          // the as-written kernel for the time being: no mode counts as numerator-folded
     int arith, mixer, sqrt_kind;
     uint32_t channels, ntaps, ntaps_pad, hist_len, tapsets;
     uint32_t osc_len;
@@ -1757,10 +1941,22 @@ static void chain_free(msdr_chain *c)
     if (c->anr) msdr_anr_destroy(c->anr);
     hipFree(c->d_anr_on);
     for (auto &e : c->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto &o : c->osc_pending) hipFree(o.d_tab);
     delete c;
 }
 
+// floors for the state bounds of a chain that is being rebuilt under a running stream (chain_rebuild): the state the OLD tables left
+// behind must fit the new tables' fp16 intake too
+static thread_local double g_chain_floor_d = 0.0, g_chain_floor_sig = 0.0;
+
+static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_chain **out);
 extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_chain **out)
+{
+    if (int rc = chain_create_impl(ctx, cfg, out)) return rc;
+    (*out)->store.capture(cfg);
+    return 0;
+}
+static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_chain **out)
 {
     if (!out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "out is null");
     *out = nullptr;
@@ -1792,7 +1988,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
         // it and run arm_biquad_cascade_df1_f32 as written behind the main kernel (one lane per channel)
         msdr_chain_config plain = *cfg;
         plain.num_biquad_stages = 0; plain.biquad_coeffs = nullptr;
-        if (int rc = msdr_chain_create(ctx, &plain, out)) return rc;
+        if (int rc = chain_create_impl(ctx, &plain, out)) return rc;
         if (int rc = msdr_biquad_df1_f32_create(ctx, (uint8_t)cfg->num_biquad_stages, cfg->biquad_coeffs, cfg->channels, &(*out)->seq_bq)) {
             msdr_chain_destroy(*out); *out = nullptr; return rc;
         }
@@ -1802,7 +1998,7 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
 
     msdr_chain *c = new (std::nothrow) msdr_chain();
     if (!c) return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed");
-    c->seq_bq = nullptr;
+    c->seq_bq = nullptr; c->own_d_bound = 0.0; c->own_sig_bound = 0.0;
     c->ctx = ctx; c->arith = cfg->arith; c->mixer = cfg->mixer; c->sqrt_kind = cfg->sqrt_kind;
     c->channels = cfg->channels; c->ntaps = cfg->num_taps; c->ntaps_pad = (cfg->num_taps + 3u) & ~3u;
     c->hist_len = c->ntaps_pad - 1; c->tapsets = cfg->num_tapsets;
@@ -2174,6 +2370,8 @@ extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, ms
                 chain_d_bound = std::max(chain_d_bound, xs);
                 chain_sig_bound = std::max(chain_sig_bound, std::max(32768.0 * oamp * f1, env * cl1) * glmax);
             }
+            c->own_d_bound = chain_d_bound; c->own_sig_bound = chain_sig_bound;
+            chain_d_bound = std::max(chain_d_bound, g_chain_floor_d); chain_sig_bound = std::max(chain_sig_bound, g_chain_floor_sig);
         }
         for (uint32_t s = 0; s < c->tapsets && ok; s++) {
             const float *hi = (const float *)cfg->coeffs_i[s], *hq = (const float *)cfg->coeffs_q[s];
@@ -2461,6 +2659,13 @@ static int chain_post_build_steps(msdr_chain *c)
     a.flags = c->flags & ~(uint32_t)MSDR_CHAIN_SYNCAM_PLL;
     if (int rc = msdr_chain_create(c->ctx, &a, &c->aux)) return rc;
     c->aux->phase = c->phase;
+    for (const auto &o : c->osc_pending) {          // the auxiliary chain takes the same raw history over: the same tables apply to it
+        msdr_chain::OscPending q{nullptr, o.elapsed};
+        const size_t bytes = (size_t)c->osc_len * 2 * sizeof(float);
+        HIP_TRY(hipMalloc(&q.d_tab, bytes));
+        HIP_TRY(hipMemcpy(q.d_tab, o.d_tab, bytes, hipMemcpyDeviceToDevice));
+        c->aux->osc_pending.push_back(q); c->aux->force_generic = true;
+    }
     if (c->h_bq_stages) {
         if (int rc = msdr_biquad_df1_f32_create(c->ctx, (uint8_t)c->h_bq_stages, c->h_bq.data(), (uint32_t)post_ch.size(), &c->post_bq)) return rc;
         if (!old_bq.empty()) {
@@ -2550,6 +2755,7 @@ static int chain_post_run(msdr_chain *c, const int16_t *d_if, float *d_audio, ui
     return launch_check("post_scatter_rows_kernel");
 }
 
+static int chain_leave_generic(msdr_chain *c);
 extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_audio, uint64_t n_samples)
 {
     if (!c) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null chain");
@@ -2588,9 +2794,17 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             p.syncam_q = c->d_pll_q;
         }
     }
-    const bool use_mf = f32 && c->mf_ok;
+    // (history samples that arrived under an earlier oscillator table are still in reach, msdr_chain_set_osc: the as-written kernel mixes
+    //  each with the table of its own time; the fast kernels come back once the history has turned over)
+    if (c->force_generic) use_fold = false;
+    const bool use_mf = f32 && c->mf_ok && !c->force_generic;
     const bool use_mfw = use_mf && c->mfw_nw > 0;
-    bool use_qm = !f32 && c->d_qm_tab != nullptr;
+    bool use_qm = !f32 && c->d_qm_tab != nullptr && !c->force_generic;
+    p.n_osc_prev = 0;
+    for (const auto &o : c->osc_pending) {
+        if (p.n_osc_prev >= 4) break;
+        p.osc_prev[p.n_osc_prev] = o.d_tab; p.osc_switch[p.n_osc_prev] = -o.elapsed; p.n_osc_prev++;
+    }
     if (use_qm)
         for (int ts : c->h_tapset) if (!c->qm_set_ok[ts]) { use_qm = false; break; }      // a tap >= 32640: the VALU kernel runs
     if (use_mf) use_fold = false;
@@ -2879,6 +3093,11 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     if (int rc = launch_check("history_kernel")) return rc;
     c->cur ^= 1; c->gen++;
     c->phase = (c->phase + (long long)(n_samples % c->osc_len)) % c->osc_len;
+    if (c->force_generic) {
+        for (auto &o : c->osc_pending) o.elapsed += (long long)n_samples;
+        if (c->osc_pending.empty() || c->osc_pending.back().elapsed >= (long long)c->hist_len)
+            if (int rc = chain_leave_generic(c)) return rc;
+    }
 
     snprintf(c->info.kernel, sizeof c->info.kernel, "%s%s", kname, c->seq_bq ? " + biquad_df1_seq_kernel" : "");
     c->info.grid = grid; c->info.block = block; c->info.lds_bytes = (uint32_t)lds;
@@ -2917,7 +3136,7 @@ extern "C" int msdr_chain_reset(msdr_chain *c)
 // reads the numerator history d[n-1-k] of the carried state.
 static bool chain_mode_folded(const msdr_chain *c, int m)
 {
-    return c->arith == MSDR_ARITH_F32 && c->mf_ok && c->nstages > 0 && (m == MSDR_MODE_LSB || m == MSDR_MODE_USB);
+    return c->arith == MSDR_ARITH_F32 && c->mf_ok && !c->force_generic && c->nstages > 0 && (m == MSDR_MODE_LSB || m == MSDR_MODE_USB);
 }
 // d[-1-k], k < 8, of an SSB mode from a channel's raw IF history (what the folded FIR implies the cascade has seen)
 static void chain_ssb_history(const msdr_chain *c, const int16_t *hist, int m, int ts, double *D)
@@ -3027,6 +3246,219 @@ extern "C" int msdr_chain_set_mode(msdr_chain *c, uint32_t channel, int32_t mode
     HIP_TRY(hipMemcpyAsync(c->d_mode + channel, &mode, sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));
     HIP_TRY(hipMemcpyAsync(c->d_tapset + channel, &tapset, sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));
     HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    return 0;
+}
+
+// ---- live updates (include/msdr.h): the chain's tables are rebuilt by msdr_chain_create from the edited configuration, every piece of
+// STATE moves from the running chain into the rebuilt one, and the two structs trade places, so the caller's handle now names the new
+// tables over the old state.  The stream is drained first: the old tables are freed with the husk.
+static int chain_rebuild(msdr_chain *c, const ChainCfgStore &edited, void **steal_osc = nullptr)
+{
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    msdr_chain_config cfg;
+    edited.view(&cfg, c->h_mode, c->h_tapset);
+    msdr_chain *n = nullptr;
+    g_chain_floor_d = c->own_d_bound; g_chain_floor_sig = c->own_sig_bound;
+    const int rc = msdr_chain_create(c->ctx, &cfg, &n);
+    g_chain_floor_d = 0.0; g_chain_floor_sig = 0.0;
+    if (rc) return rc;
+    if (n->hist_len != c->hist_len || n->channels != c->channels || n->osc_len != c->osc_len) {
+        chain_free(n);
+        return fail(MSDR_STATUS_SIZE_MISMATCH, "internal: a live update changed the chain's geometry");
+    }
+    // FIR history and table position
+    std::swap(n->d_hist[0], c->d_hist[0]); std::swap(n->d_hist[1], c->d_hist[1]); n->cur = c->cur; n->phase = c->phase;
+    // fp32 cascade state (the callers that change the cascade itself rewrite it afterwards)
+    if (n->d_bq_state && c->d_bq_state) std::swap(n->d_bq_state, c->d_bq_state);
+    if (n->seq_bq && c->seq_bq) std::swap(n->seq_bq, c->seq_bq);
+    // Teensy biquad nodes (coefficients and history both live in their records), PLL, LMS filter
+    for (int k = 0; k < 2; k++) if (n->nodes[k] && c->nodes[k]) std::swap(n->nodes[k], c->nodes[k]);
+    std::swap(n->pll, c->pll); std::swap(n->d_pll_q, c->d_pll_q); std::swap(n->pll_q_cap, c->pll_q_cap);
+    std::swap(n->anr, c->anr); std::swap(n->d_anr_on, c->d_anr_on); n->anr_all = c->anr_all;
+    // fp32 post channels: per-channel PLL / LMS state and the post cascade persist; the auxiliary chain is rebuilt from the new
+    // configuration at the next call and takes the history over from d_hist (chain_post_build_steps)
+    n->h_anr = c->h_anr; n->anr_gen = c->anr_gen; n->f32_pll = c->f32_pll;
+    std::swap(n->d_post_pll_state, c->d_post_pll_state); std::swap(n->d_post_anr_state, c->d_post_anr_state);
+    std::swap(n->post_bq, c->post_bq); n->h_post_ch = c->h_post_ch; c->h_post_ch.clear();
+    n->post_mode_gen = 0; n->post_anr_gen = 0;
+    // bookkeeping of the stream
+    n->gen = c->gen; n->dh_cache = c->dh_cache; n->dh_gen = c->dh_gen;
+    n->timing = c->timing; n->events.swap(c->events); n->timed_ms = c->timed_ms; n->timed_launches = c->timed_launches;
+    n->info = c->info;
+    n->osc_pending.swap(c->osc_pending); n->force_generic = c->force_generic;
+    std::swap(*c, *n);
+    if (steal_osc) { *steal_osc = n->d_osc; n->d_osc = nullptr; }
+    chain_free(n);
+    return 0;
+}
+
+// The history has turned over since the last oscillator change: the fast kernels take the stream back.  A mode whose table folds the
+// cascade's numerator into the FIR takes its state record the other way round (first-sample corrections instead of the history).
+static int chain_leave_generic(msdr_chain *c)
+{
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    for (auto &o : c->osc_pending) hipFree(o.d_tab);
+    c->osc_pending.clear();
+    if (!c->force_generic) return 0;
+    c->force_generic = false;
+    bool any = false;
+    for (uint32_t ch = 0; ch < c->channels && !any; ch++) any = chain_mode_folded(c, c->h_mode[ch]);
+    if (!any || !c->d_bq_state) return 0;
+    std::vector<int16_t> hist((size_t)c->channels * c->hist_len);
+    std::vector<float> st((size_t)c->channels * kBqStateFloats);
+    HIP_TRY(hipMemcpy(hist.data(), c->d_hist[c->cur], hist.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(st.data(), c->d_bq_state, st.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (uint32_t ch = 0; ch < c->channels; ch++) {
+        if (!chain_mode_folded(c, c->h_mode[ch])) continue;
+        float *r = st.data() + (size_t)ch * kBqStateFloats;
+        double D[8], Dn[8];
+        for (int k = 0; k < 8; k++) D[k] = r[k];
+        chain_ssb_history(c, hist.data() + (size_t)ch * c->hist_len, c->h_mode[ch], c->h_tapset[ch], Dn);
+        chain_folded_correction(c, D, Dn, r);
+        memcpy(c->dh_cache[ch].v, D, sizeof D); c->dh_gen[ch] = c->gen;
+    }
+    HIP_TRY(hipMemcpy(c->d_bq_state, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// A rebuild that changes what a numerator-folded SSB table implies about the cascade's input history (new taps, new oscillator):
+// the true history D (old tables) is handed over as first-sample corrections against the history Dn the new tables imply, exactly as a
+// retune does (msdr_chain_set_mode).  affected(ch): the channel's FIR or oscillator changes.
+static int chain_rebuild_keep_folded(msdr_chain *c, const ChainCfgStore &edited, const std::function<bool(uint32_t)> &affected, bool osc_changes = false)
+{
+    std::vector<uint32_t> fix;
+    if (c->arith == MSDR_ARITH_F32 && c->d_bq_state)
+        for (uint32_t ch = 0; ch < c->channels; ch++) if (chain_mode_folded(c, c->h_mode[ch]) && affected(ch)) fix.push_back(ch);
+    std::vector<int16_t> hist;
+    std::vector<float> st;
+    std::vector<double> Dall;
+    if (!fix.empty()) {
+        HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+        hist.resize((size_t)c->channels * c->hist_len); st.resize((size_t)c->channels * kBqStateFloats); Dall.resize((size_t)c->channels * 8);
+        HIP_TRY(hipMemcpy(hist.data(), c->d_hist[c->cur], hist.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(st.data(), c->d_bq_state, st.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (uint32_t ch : fix) chain_true_history(c, ch, hist.data() + (size_t)ch * c->hist_len, st.data() + (size_t)ch * kBqStateFloats, Dall.data() + (size_t)ch * 8);
+    }
+    void *old_osc = nullptr;
+    if (int rc = chain_rebuild(c, edited, osc_changes ? &old_osc : nullptr)) return rc;
+    if (osc_changes) {
+        // the samples in the FIR history were mixed with the old tables when they arrived: keep those for as long as the history holds
+        // such samples (at most 4 generations; a fifth change inside one history length drops the oldest)
+        if (c->osc_pending.size() >= 4) { hipFree(c->osc_pending.front().d_tab); c->osc_pending.erase(c->osc_pending.begin()); }
+        c->osc_pending.push_back(msdr_chain::OscPending{old_osc, 0});
+        c->force_generic = true;
+    }
+    if (!fix.empty() && c->d_bq_state) {
+        for (uint32_t ch : fix) {
+            float *r = st.data() + (size_t)ch * kBqStateFloats;
+            const double *D = Dall.data() + (size_t)ch * 8;
+            if (chain_mode_folded(c, c->h_mode[ch])) {
+                double Dn[8];
+                chain_ssb_history(c, hist.data() + (size_t)ch * c->hist_len, c->h_mode[ch], c->h_tapset[ch], Dn);
+                chain_folded_correction(c, D, Dn, r);
+            } else for (int k = 0; k < 8; k++) r[k] = (float)D[k];       // (the rebuilt chain does not fold this mode any more)
+            HIP_TRY(hipMemcpy(c->d_bq_state + (size_t)ch * kBqStateFloats, r, 8 * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
+    return 0;
+}
+
+extern "C" int msdr_chain_set_taps(msdr_chain *c, uint32_t tapset, const void *coeffs_i, const void *coeffs_q)
+{
+    if (!c || !coeffs_i || !coeffs_q) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    if (int rc = bind(c->ctx)) return rc;
+    if (tapset >= c->tapsets) return fail(MSDR_STATUS_ARGUMENT_ERROR, "tap set %u of %u", tapset, c->tapsets);
+    ChainCfgStore ed = c->store;
+    const size_t bytes = ed.ci[tapset].size();
+    ed.ci[tapset].assign((const char *)coeffs_i, (const char *)coeffs_i + bytes);
+    ed.cq[tapset].assign((const char *)coeffs_q, (const char *)coeffs_q + bytes);
+    return chain_rebuild_keep_folded(c, ed, [&](uint32_t ch) { return (uint32_t)c->h_tapset[ch] == tapset; });
+}
+
+extern "C" int msdr_chain_set_osc(msdr_chain *c, const void *osc_i, const void *osc_q)
+{
+    if (!c || !osc_i || !osc_q) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    if (int rc = bind(c->ctx)) return rc;
+    if (c->mixer != MSDR_MIXER_NCO) return fail(MSDR_STATUS_ARGUMENT_ERROR, "this chain has the Fs/4 mixer: no oscillator tables (Minimal-SDR.ino:546-558)");
+    ChainCfgStore ed = c->store;
+    const size_t bytes = ed.osc_i.size();
+    ed.osc_i.assign((const char *)osc_i, (const char *)osc_i + bytes);
+    ed.osc_q.assign((const char *)osc_q, (const char *)osc_q + bytes);
+    return chain_rebuild_keep_folded(c, ed, [](uint32_t) { return true; }, true);
+}
+
+extern "C" int msdr_chain_set_node_coefficients(msdr_chain *c, uint32_t node, uint32_t stage, const int32_t coef[5])
+{
+    if (!c || !coef) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    if (int rc = bind(c->ctx)) return rc;
+    if (c->arith != MSDR_ARITH_Q15) return fail(MSDR_STATUS_ARGUMENT_ERROR, "AudioFilterBiquad nodes belong to Q15 chains (fp32: msdr_chain_set_biquad_coeffs)");
+    if (node >= c->nnodes || !c->nodes[node]) return fail(MSDR_STATUS_ARGUMENT_ERROR, "node %u of %u", node, c->nnodes);
+    if (stage >= 4) return 0;                                                 // filter_biquad.cpp:86
+    if (int rc = msdr_biquad_q15_set_coefficients(c->nodes[node], stage, coef)) return rc;
+    std::vector<int32_t> &h = c->store.node[node];                              // keep the stored configuration in step
+    if (h.size() < 5 * (size_t)(stage + 1)) h.resize(5 * (size_t)(stage + 1), 0);
+    memcpy(h.data() + 5 * stage, coef, 5 * sizeof(int32_t));
+    c->store.cfg.node_stages[node] = std::max<uint32_t>(c->store.cfg.node_stages[node], stage + 1);
+    return 0;
+}
+
+// arm_biquad_cascade_df1_f32's pCoeffs rewritten under the running stream: state kept in CMSIS terms (msdr_cascade_state.h)
+extern "C" int msdr_chain_set_biquad_coeffs(msdr_chain *c, const float32_t *coeffs)
+{
+    if (!c || !coeffs) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    if (int rc = bind(c->ctx)) return rc;
+    if (c->arith != MSDR_ARITH_F32) return fail(MSDR_STATUS_ARGUMENT_ERROR, "the fp32 cascade belongs to F32 chains (Q15: msdr_chain_set_node_coefficients)");
+    const int S = (int)c->h_bq_stages, ny = 2 * S + 2;
+    if (S == 0) return fail(MSDR_STATUS_ARGUMENT_ERROR, "this chain was created without a biquad cascade (numStages is fixed at creation, as in CMSIS)");
+    for (int k = 0; k < 5 * S; k++) if (!std::isfinite(coeffs[k])) return fail(MSDR_STATUS_ARGUMENT_ERROR, "coefficient %d is not finite", k);
+    cstate::Bridge br;
+    br.build(c->h_bq.data(), coeffs, S);
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    // ---- every channel's state in CMSIS terms, and the cascade's true input history ----
+    std::vector<double> Y((size_t)c->channels * ny, 0.0), D((size_t)c->channels * 8, 0.0);
+    std::vector<int16_t> hist((size_t)c->channels * c->hist_len);
+    HIP_TRY(hipMemcpy(hist.data(), c->d_hist[c->cur], hist.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+    if (c->seq_bq) {
+        if (int rc = biquad_df1_read_cmsis(c->seq_bq, br, Y, D)) return rc;
+    } else {
+        if (!br.ok_to) return fail(MSDR_STATUS_ARGUMENT_ERROR, "the running cascade's block-parallel state has no unique CMSIS state (a numerator shares a root with an earlier denominator)");
+        std::vector<float> st((size_t)c->channels * kBqStateFloats);
+        HIP_TRY(hipMemcpy(st.data(), c->d_bq_state, st.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (uint32_t ch = 0; ch < c->channels; ch++) {
+            double *d = D.data() + (size_t)ch * 8;
+            chain_true_history(c, ch, hist.data() + (size_t)ch * c->hist_len, st.data() + (size_t)ch * kBqStateFloats, d);
+            br.lib_to_cmsis(d, st.data() + (size_t)ch * kBqStateFloats, Y.data() + (size_t)ch * ny);
+        }
+    }
+    // ---- the rebuilt chain ----
+    const bool new_seq = cascade_needs_cmsis_order(coeffs, S);
+    if (!new_seq && !br.ok_from) return fail(MSDR_STATUS_ARGUMENT_ERROR, "no block-parallel state reproduces the CMSIS state under the new coefficients");
+    ChainCfgStore ed = c->store;
+    ed.bq.assign(coeffs, coeffs + 5 * S);
+    msdr_biquad_df1_f32 *old_seq = c->seq_bq;          // (chain_rebuild would swap the old object in: the new one must stay)
+    c->seq_bq = nullptr;
+    const int rrc = chain_rebuild(c, ed);
+    if (rrc) { c->seq_bq = old_seq; return rrc; }
+    if (old_seq) msdr_biquad_df1_f32_destroy(old_seq);
+    if (c->seq_bq) {
+        if (int rc = biquad_df1_write_cmsis(c->seq_bq, br, Y, D)) return rc;
+    } else {
+        std::vector<float> st((size_t)c->channels * kBqStateFloats, 0.0f);
+        for (uint32_t ch = 0; ch < c->channels; ch++) {
+            float *r = st.data() + (size_t)ch * kBqStateFloats;
+            const double *d = D.data() + (size_t)ch * 8;
+            br.cmsis_to_lib(Y.data() + (size_t)ch * ny, d, r + 8);
+            if (chain_mode_folded(c, c->h_mode[ch])) {
+                double Dn[8];
+                chain_ssb_history(c, hist.data() + (size_t)ch * c->hist_len, c->h_mode[ch], c->h_tapset[ch], Dn);
+                chain_folded_correction(c, d, Dn, r);
+            } else for (int k = 0; k < 2 * S; k++) r[k] = (float)d[k];
+            memcpy(c->dh_cache[ch].v, d, 8 * sizeof(double)); c->dh_gen[ch] = c->gen;
+        }
+        HIP_TRY(hipMemcpy(c->d_bq_state, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // the post channels' own cascade (rows f2 / f3 inside the fp32 chain)
+    if (c->post_bq) if (int rc = msdr_biquad_df1_f32_set_coeffs(c->post_bq, coeffs)) return rc;
     return 0;
 }
 

@@ -4,10 +4,15 @@
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 namespace {
 
-struct Entry { int kind; void *handle; };          // kind: 0 fir q15, 1 fir f32, 2 biquad df1 f32
+// kind: 0 fir q15, 1 fir f32, 2 biquad df1 f32.  coef: the bytes of pCoeffs the device tables were last built from -- CMSIS reads
+// the caller's array on every call (the instance holds a pointer, arm_fir_init_q15.c:100-109), and the reference rewrites it in place
+// under the running filter (UI.cpp:337-345, Minimal-SDR.ino:221-223), so every process call compares and, on a change, rebuilds the
+// tables with the filter state kept (msdr_fir_*_set_coeffs, msdr_biquad_df1_f32_set_coeffs).
+struct Entry { int kind; void *handle; std::vector<char> coef; };
 struct Binding {
     std::mutex mu;
     msdr_ctx *ctx = nullptr;
@@ -23,12 +28,13 @@ void destroy(const Entry &e)
     else msdr_biquad_df1_f32_destroy((msdr_biquad_df1_f32 *)e.handle);
 }
 // registers (or replaces: a re-init of the same instance) the device object behind S
-void remember(const void *S, int kind, void *handle)
+void remember(const void *S, int kind, void *handle, const void *coef, size_t coef_bytes)
 {
     Binding &b = binding();
+    std::vector<char> snap((const char *)coef, (const char *)coef + (coef ? coef_bytes : 0));
     auto it = b.inst.find(S);
-    if (it != b.inst.end()) { destroy(it->second); it->second = Entry{kind, handle}; }
-    else b.inst.emplace(S, Entry{kind, handle});
+    if (it != b.inst.end()) { destroy(it->second); it->second = Entry{kind, handle, std::move(snap)}; }
+    else b.inst.emplace(S, Entry{kind, handle, std::move(snap)});
 }
 // a failed (re-)init: the instance struct already shows the new filter, so the OLD device object must not answer for it any more --
 // later process calls on S do nothing and msdr_last_error() holds the create's text
@@ -40,11 +46,18 @@ void forget(const void *S)
 }
 // (caller holds the lock, and keeps it across the process call: a concurrent re-init or msdr_cmsis_bind cannot destroy the object
 //  under a running enqueue -- process calls only queue work on the context's stream, so the lock is held for microseconds)
-void *lookup_locked(const void *S, int kind)
+Entry *lookup_locked(const void *S, int kind)
 {
     Binding &b = binding();
     auto it = b.inst.find(S);
-    return (it != b.inst.end() && it->second.kind == kind) ? it->second.handle : nullptr;
+    return (it != b.inst.end() && it->second.kind == kind) ? &it->second : nullptr;
+}
+// the caller's coefficient array against the snapshot; true = changed (and the snapshot now holds the new bytes)
+bool coeffs_changed(Entry *e, const void *pCoeffs)
+{
+    if (!pCoeffs || e->coef.empty() || memcmp(e->coef.data(), pCoeffs, e->coef.size()) == 0) return false;
+    memcpy(e->coef.data(), pCoeffs, e->coef.size());
+    return true;
 }
 
 }  // namespace
@@ -80,13 +93,16 @@ extern "C" msdr_arm_status msdr_arm_fir_init_q15(msdr_arm_fir_instance_q15 *S, u
     std::lock_guard<std::mutex> g(b.mu);
     msdr_fir_q15 *h = nullptr;
     if (!b.ctx || msdr_fir_q15_create(b.ctx, numTaps, pCoeffs, b.channels, &h) != 0) { forget(S); return MSDR_ARM_MATH_ARGUMENT_ERROR; }
-    remember(S, 0, h);
+    remember(S, 0, h, pCoeffs, (size_t)numTaps * sizeof(q15_t));
     return MSDR_ARM_MATH_SUCCESS;
 }
 extern "C" void msdr_arm_fir_fast_q15(const msdr_arm_fir_instance_q15 *S, q15_t *pSrc, q15_t *pDst, uint32_t blockSize)
 {
     std::lock_guard<std::mutex> g(binding().mu);
-    if (void *h = lookup_locked(S, 0)) (void)msdr_fir_q15_process((msdr_fir_q15 *)h, pSrc, pDst, blockSize);
+    Entry *e = lookup_locked(S, 0);
+    if (!e) return;
+    if (coeffs_changed(e, S->pCoeffs) && msdr_fir_q15_set_coeffs((msdr_fir_q15 *)e->handle, S->pCoeffs) != 0) return;
+    (void)msdr_fir_q15_process((msdr_fir_q15 *)e->handle, pSrc, pDst, blockSize);
 }
 
 extern "C" void msdr_arm_fir_init_f32(msdr_arm_fir_instance_f32 *S, uint16_t numTaps, float32_t *pCoeffs, float32_t *pState, uint32_t blockSize)
@@ -96,13 +112,16 @@ extern "C" void msdr_arm_fir_init_f32(msdr_arm_fir_instance_f32 *S, uint16_t num
     Binding &b = binding();
     std::lock_guard<std::mutex> g(b.mu);
     msdr_fir_f32 *h = nullptr;
-    if (b.ctx && msdr_fir_f32_create(b.ctx, numTaps, pCoeffs, b.channels, &h) == 0) remember(S, 1, h);
+    if (b.ctx && msdr_fir_f32_create(b.ctx, numTaps, pCoeffs, b.channels, &h) == 0) remember(S, 1, h, pCoeffs, (size_t)numTaps * sizeof(float32_t));
     else forget(S);
 }
 extern "C" void msdr_arm_fir_f32(const msdr_arm_fir_instance_f32 *S, float32_t *pSrc, float32_t *pDst, uint32_t blockSize)
 {
     std::lock_guard<std::mutex> g(binding().mu);
-    if (void *h = lookup_locked(S, 1)) (void)msdr_fir_f32_process((msdr_fir_f32 *)h, pSrc, pDst, blockSize);
+    Entry *e = lookup_locked(S, 1);
+    if (!e) return;
+    if (coeffs_changed(e, S->pCoeffs) && msdr_fir_f32_set_coeffs((msdr_fir_f32 *)e->handle, S->pCoeffs) != 0) return;
+    (void)msdr_fir_f32_process((msdr_fir_f32 *)e->handle, pSrc, pDst, blockSize);
 }
 
 extern "C" void msdr_arm_biquad_cascade_df1_init_f32(msdr_arm_biquad_casd_df1_inst_f32 *S, uint8_t numStages, float32_t *pCoeffs, float32_t *pState)
@@ -112,11 +131,14 @@ extern "C" void msdr_arm_biquad_cascade_df1_init_f32(msdr_arm_biquad_casd_df1_in
     Binding &b = binding();
     std::lock_guard<std::mutex> g(b.mu);
     msdr_biquad_df1_f32 *h = nullptr;
-    if (b.ctx && msdr_biquad_df1_f32_create(b.ctx, numStages, pCoeffs, b.channels, &h) == 0) remember(S, 2, h);
+    if (b.ctx && msdr_biquad_df1_f32_create(b.ctx, numStages, pCoeffs, b.channels, &h) == 0) remember(S, 2, h, pCoeffs, (size_t)5 * numStages * sizeof(float32_t));
     else forget(S);
 }
 extern "C" void msdr_arm_biquad_cascade_df1_f32(const msdr_arm_biquad_casd_df1_inst_f32 *S, float32_t *pSrc, float32_t *pDst, uint32_t blockSize)
 {
     std::lock_guard<std::mutex> g(binding().mu);
-    if (void *h = lookup_locked(S, 2)) (void)msdr_biquad_df1_f32_process((msdr_biquad_df1_f32 *)h, pSrc, pDst, blockSize);
+    Entry *e = lookup_locked(S, 2);
+    if (!e) return;
+    if (coeffs_changed(e, S->pCoeffs) && msdr_biquad_df1_f32_set_coeffs((msdr_biquad_df1_f32 *)e->handle, S->pCoeffs) != 0) return;
+    (void)msdr_biquad_df1_f32_process((msdr_biquad_df1_f32 *)e->handle, pSrc, pDst, blockSize);
 }

@@ -94,6 +94,12 @@ struct ChainParams {
     int dbg;                   // diagnostic bits: read from MSDR_DBG by the -DMSDR_STAMPS build only; the product build never looks at it
     const float *mw_iir;       // wave-stream kernel, folded IIR: MwIirConsts block (scan matrices, response fragments), or null
     float *bq_state_out;       // [channels][kBqStateFloats] cascade state after this call (ping-pong partner of bq_state)
+    // chain_kernel<Arith> only: oscillator tables that were in force before a live change (msdr_chain_set_osc), oldest first -- a carried
+    // history sample at time t < osc_switch[k] (t relative to this call, so osc_switch <= 0) was mixed with table k when it arrived
+    // (freq_conv.cpp:70-103 mixes each block with the tables as they are at that update()), and is mixed with it again here
+    const void *osc_prev[4];
+    long long osc_switch[4];
+    int n_osc_prev;
 };
 
 }  // namespace msdr

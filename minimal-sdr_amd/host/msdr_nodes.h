@@ -256,6 +256,17 @@ public:
     }
     int init_FIR(void) { return chain ? msdr_chain_init_fir(chain) : MSDR_STATUS_ARGUMENT_ERROR; }     // Minimal-SDR.ino:901-930
     int setMode(uint32_t channel, int mode, int tapset) { return chain ? msdr_chain_set_mode(chain, channel, mode, tapset) : MSDR_STATUS_ARGUMENT_ERROR; }
+    // what the sketch changes while audio plays, filter state kept (include/msdr.h "live updates"):
+    // calc_demod_filter() rewriting FIR_AM_coeffs (Minimal-SDR.ino:221-223), tune()'s biquad2_dac.setNotch (:356), new oscillator tables (freq_conv.h:33-34)
+    int setTaps(uint32_t tapset, const void *coeffs_i, const void *coeffs_q) { return chain ? msdr_chain_set_taps(chain, tapset, coeffs_i, coeffs_q) : MSDR_STATUS_ARGUMENT_ERROR; }
+    int setNodeCoefficients(uint32_t node, uint32_t stage, const int *coef) { return chain ? msdr_chain_set_node_coefficients(chain, node, stage, (const int32_t *)coef) : MSDR_STATUS_ARGUMENT_ERROR; }
+    int setNodeNotch(uint32_t node, uint32_t stage, float frequency, float q = 1.0f)
+    {
+        int32_t coef[5];
+        if (int rc = msdr_biquad_design(MSDR_BQ_NOTCH, frequency, q, 1.0f, AUDIO_SAMPLE_RATE_EXACT, coef)) return rc;
+        return setNodeCoefficients(node, stage, (const int *)coef);
+    }
+    int setOsc(const void *osc_i, const void *osc_q) { return chain ? msdr_chain_set_osc(chain, osc_i, osc_q) : MSDR_STATUS_ARGUMENT_ERROR; }
     virtual void update(void)
     {
         audio_block_t *in = receiveReadOnly();

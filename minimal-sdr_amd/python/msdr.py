@@ -72,6 +72,16 @@ def load_library(path=None):
         _lib.msdr_calc_FIR_coeffs_pid.argtypes = [_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
         _lib.msdr_biquad_design.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_double, _p]
         _lib.msdr_biquad_df1_f32_cascade_info.argtypes = [C.c_uint8, _p, _p, _p, _p]
+        _lib.msdr_biquad_df1_f32_state_to_cmsis.argtypes = [C.c_uint8, _p, _p, _p]
+        _lib.msdr_biquad_df1_f32_state_from_cmsis.argtypes = [C.c_uint8, _p, _p, _p]
+        _lib.msdr_biquad_df1_f32_set_coeffs.argtypes = [_p, _p]
+        _lib.msdr_biquad_df1_f32_get_cmsis_state.argtypes = [_p, C.c_uint32, _p]
+        _lib.msdr_fir_q15_set_coeffs.argtypes = [_p, _p]
+        _lib.msdr_fir_f32_set_coeffs.argtypes = [_p, _p]
+        _lib.msdr_chain_set_taps.argtypes = [_p, C.c_uint32, _p, _p]
+        _lib.msdr_chain_set_osc.argtypes = [_p, _p, _p]
+        _lib.msdr_chain_set_node_coefficients.argtypes = [_p, C.c_uint32, C.c_uint32, _p]
+        _lib.msdr_chain_set_biquad_coeffs.argtypes = [_p, _p]
         _lib.msdr_malloc.argtypes = [_p, C.c_size_t, _p]
         _lib.msdr_free.argtypes = [_p, _p]
         _lib.msdr_memcpy_h2d.argtypes = [_p, _p, _p, C.c_size_t]
@@ -138,6 +148,26 @@ def biquad_cascade_info(coeffs):
     k, nz, seq = C.c_double(0), C.c_double(0), C.c_int(0)
     _ck(load_library().msdr_biquad_df1_f32_cascade_info(C.c_uint8(c.size // 5), _hp(c) if c.size else None, C.byref(k), C.byref(nz), C.byref(seq)))
     return k.value, nz.value, bool(seq.value)
+
+
+def biquad_state_to_cmsis(coeffs, lib_state):
+    """The block-parallel kernels' 16-float state record -> arm_biquad_cascade_df1_f32's pState (4 per stage) -- host only."""
+    c = np.ascontiguousarray(coeffs, np.float32).reshape(-1)
+    st = np.ascontiguousarray(lib_state, np.float32).reshape(16)
+    out = np.zeros(4 * (c.size // 5), np.float32)
+    _ck(load_library().msdr_biquad_df1_f32_state_to_cmsis(C.c_uint8(c.size // 5), _hp(c), _hp(st), _hp(out)))
+    return out
+
+
+def biquad_state_from_cmsis(coeffs, pstate, d_hist=None):
+    """pState -> the 16-float record (entries 0..7: the cascade's input history, taken from d_hist beyond the two newest)."""
+    c = np.ascontiguousarray(coeffs, np.float32).reshape(-1)
+    ps = np.ascontiguousarray(pstate, np.float32).reshape(-1)
+    st = np.zeros(16, np.float32)
+    if d_hist is not None:
+        st[:len(d_hist)] = d_hist
+    _ck(load_library().msdr_biquad_df1_f32_state_from_cmsis(C.c_uint8(c.size // 5), _hp(c), _hp(ps), _hp(st)))
+    return st
 
 
 class DeviceView:
@@ -299,6 +329,11 @@ class FirQ15(_Instance):
     def reset(self):
         _ck(self.ctx.lib.msdr_fir_q15_reset(self.h))
 
+    def set_coeffs(self, coeffs):
+        """pCoeffs rewritten under the running filter (UI.cpp:337-345): state kept."""
+        c = np.ascontiguousarray(coeffs, np.int16)
+        _ck(self.ctx.lib.msdr_fir_q15_set_coeffs(self.h, _hp(c)))
+
 
 class FirF32(_Instance):
     """arm_fir_init_f32 / arm_fir_f32, batched over channels."""
@@ -316,6 +351,10 @@ class FirF32(_Instance):
 
     def reset(self):
         _ck(self.ctx.lib.msdr_fir_f32_reset(self.h))
+
+    def set_coeffs(self, coeffs):
+        c = np.ascontiguousarray(coeffs, np.float32)
+        _ck(self.ctx.lib.msdr_fir_f32_set_coeffs(self.h, _hp(c)))
 
     def set_input_range(self, max_abs):
         _ck(self.ctx.lib.msdr_fir_f32_set_input_range(self.h, C.c_float(max_abs)))
@@ -344,6 +383,16 @@ class BiquadDf1F32(_Instance):
 
     def reset(self):
         _ck(self.ctx.lib.msdr_biquad_df1_f32_reset(self.h))
+
+    def set_coeffs(self, coeffs):
+        """pCoeffs rewritten under the running cascade: continues from CMSIS' pState."""
+        c = np.ascontiguousarray(coeffs, np.float32).reshape(-1)
+        _ck(self.ctx.lib.msdr_biquad_df1_f32_set_coeffs(self.h, _hp(c)))
+
+    def cmsis_state(self, channel, stages):
+        out = np.zeros(4 * stages, np.float32)
+        _ck(self.ctx.lib.msdr_biquad_df1_f32_get_cmsis_state(self.h, C.c_uint32(channel), _hp(out)))
+        return out
 
 
 class BiquadQ15(_Instance):
@@ -567,6 +616,25 @@ class Chain(_Instance):
     def set_anr(self, anr_on=None, anr_on_all=0):
         a = np.ascontiguousarray(anr_on, np.int32) if anr_on is not None else None
         _ck(self.ctx.lib.msdr_chain_set_anr(self.h, _hp(a), C.c_int32(anr_on_all)))
+
+    # ---- live updates, every filter state kept (include/msdr.h) ----
+    def set_taps(self, tapset, coeffs_i, coeffs_q):
+        tdt = np.float32 if self.arith == ARITH_F32 else np.int16
+        ci, cq = np.ascontiguousarray(coeffs_i, tdt), np.ascontiguousarray(coeffs_q, tdt)
+        _ck(self.ctx.lib.msdr_chain_set_taps(self.h, C.c_uint32(tapset), _hp(ci), _hp(cq)))
+
+    def set_osc(self, osc_i, osc_q):
+        tdt = np.float32 if self.arith == ARITH_F32 else np.int16
+        oi, oq = np.ascontiguousarray(osc_i, tdt), np.ascontiguousarray(osc_q, tdt)
+        _ck(self.ctx.lib.msdr_chain_set_osc(self.h, _hp(oi), _hp(oq)))
+
+    def set_node_coefficients(self, node, stage, coef):
+        c = np.ascontiguousarray(coef, np.int32)
+        _ck(self.ctx.lib.msdr_chain_set_node_coefficients(self.h, C.c_uint32(node), C.c_uint32(stage), _hp(c)))
+
+    def set_biquad_coeffs(self, coeffs):
+        c = np.ascontiguousarray(coeffs, np.float32).reshape(-1)
+        _ck(self.ctx.lib.msdr_chain_set_biquad_coeffs(self.h, _hp(c)))
 
     def info(self):
         i = ChainInfo()

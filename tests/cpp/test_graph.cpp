@@ -183,6 +183,22 @@ int main(int argc, char **argv)
     for (int tick = 0; tick < 12; tick++) {
         for (auto &v : x) v = (int16_t)((rand() % 24001) - 12000);
         if (tick == 5) for (auto &v : x) v = (int16_t)((rand() & 1) ? 32767 : -32768);   // full scale
+        if (tick == 6) {
+            // the bandwidth menu: calc_demod_filter() rewrites FIR_AM_coeffs IN PLACE, no init_FIR() (UI.cpp:332-345, Minimal-SDR.ino:221-223);
+            // the oracle's instances hold the pointer, like the reference's (arm_fir_init_q15.c:100-109)
+            msdr_calc_FIR_coeffs(FIR_AM_coeffs, 102, 2025, 70, 0, 0.0, 24000);
+            CHECK(msdr_fir_q15_set_coeffs(FIR_I, FIR_AM_coeffs) == 0 && msdr_fir_q15_set_coeffs(FIR_Q, FIR_AM_coeffs) == 0, "set_coeffs: %s", msdr_last_error());
+            CHECK(demod_b.setTaps(0, FIR_AM_coeffs, FIR_AM_coeffs) == 0, "demod_b.setTaps: %s", msdr_last_error());
+        }
+        if (tick == 9) {
+            // tune(): biquad2_dac.setNotch(0, pdb_freq_actual / 8.0 * CORR_FACT, 15.0) on the running graph (Minimal-SDR.ino:356)
+            const float f = (float)(23200.0 / 8 * CORR_FACT);
+            biquad2_dac.setNotch(0, f, 15.0);
+            CHECK(demod_b.setNodeNotch(1, 0, f, 15.0f) == 0, "demod_b.setNodeNotch: %s", msdr_last_error());
+            int32_t nt2[5];
+            msdr_biquad_design(MSDR_BQ_NOTCH, f, 15.0f, 1.0f, AUDIO_SAMPLE_RATE_EXACT, nt2);
+            for (uint32_t c = 0; c < CH; c++) orc_biquad_teensy_set_coefficients(&st[c].bq[1], 0, nt2);
+        }
         adc1.next = x.data(); adc_b.next = x.data();
         AudioStream::update_all();           // tick 1: source -> queue_adc, fused node runs
         demodulation();                      // main loop

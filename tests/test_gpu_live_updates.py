@@ -1,0 +1,407 @@
+"""Live coefficient / table updates under a running stream, every filter state kept -- what the reference changes while it plays:
+
+  * the bandwidth menu rewrites FIR_AM_coeffs IN PLACE with no init_FIR() (UI.cpp:332-345 -> calc_demod_filter, Minimal-SDR.ino:221-223);
+    the running arm_fir_fast_q15 picks the new taps up on its next block with its state intact (the instance holds a pointer,
+    arm_fir_init_q15.c:100-109): msdr_chain_set_taps, msdr_fir_*_set_coeffs, the CMSIS shim's pCoeffs compare;
+  * tune() re-programs biquad2_dac on every retune (Minimal-SDR.ino:356 -> filter_biquad.cpp:84-100, history kept :95-97):
+    msdr_chain_set_node_coefficients; for the fp32 cascade msdr_chain_set_biquad_coeffs / msdr_biquad_df1_f32_set_coeffs keep
+    arm_biquad_cascade_df1_f32's pState;
+  * AudioEffectFreqConv reads the global oscillator tables on every update() (freq_conv.h:33-34, freq_conv.cpp:70-103): msdr_chain_set_osc.
+
+The oracle does what the reference does: it keeps its state and is handed the changed coefficient arrays on the next call.
+Q15: bit-exact.  fp32: relative RMS < 1e-5 per channel and per stretch between two changes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orclib
+from gpuhelp import ctx, msdr, rel_rms  # noqa: F401
+from test_gpu_chain import _f32_biquads, _hilbert_pair, _q15_nco, _ref_nodes, run_chain, CORR
+
+pytestmark = pytest.mark.gpu
+B = 128
+TOL = 1e-5
+COS4, SIN4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+
+
+def _am_taps(orc, n, bw):
+    """calc_demod_filter(): calc_FIR_coeffs(FIR_AM_coeffs, FIR_AM_num_taps, filter_bandwidth, 70, 0, 0.0, SAMPLE_RATE)"""
+    return orc.calc_fir_coeffs(n, float(bw))[:n].copy()
+
+
+# ------------------------------------------------------------------------------------------------ Q15 chain
+@pytest.mark.parametrize("flags", [0, msdr.CHAIN_NO_MFMA])
+def test_q15_chain_bandwidth_change_under_running_stream(ctx, orc, flags):
+    """filter_bandwidth stepped through the menu while audio plays: new AM taps every few blocks, FIR state and both biquad
+    nodes' history kept.  Two tap sets in use, only one of them rewritten."""
+    rng = np.random.default_rng(1)
+    ch, nt = 67, 102
+    lp, notch = _ref_nodes(orc)
+    bws = [2400, 2425, 3000, 125, 5000, 2400]
+    am, ssb_i, ssb_q = _am_taps(orc, nt, bws[0]), _am_taps(orc, nt, 1800), _am_taps(orc, nt, 900)
+    modes = rng.choice([orclib.AM, orclib.LSB, orclib.USB], ch).astype(np.int32)
+    tapsets = np.where(modes == orclib.AM, 0, 1).astype(np.int32)
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, [am, ssb_i], [am, ssb_q], modes=modes, tapsets=tapsets, biquad_nodes=[[lp], [notch]], flags=flags)
+    watch = [0, 1, 2, 33, 64, 66]
+    states = {c: {} for c in watch}
+    for k, bw in enumerate(bws):
+        if k:
+            am = _am_taps(orc, nt, bw)
+            chain.set_taps(0, am, am)
+        x = rng.integers(-20000, 20001, (ch, (3 + k) * B)).astype(np.int16)
+        got = run_chain(ctx, chain, x, np.int16, block=B if k % 2 else None)
+        for c in watch:
+            ti, tq = (am, am) if tapsets[c] == 0 else (ssb_i, ssb_q)
+            want = orc.chain_q15(x[c], int(modes[c]), ti, tq, biquads=[orc.biquad_teensy_new([lp]), orc.biquad_teensy_new([notch])], state=states[c])
+            assert np.array_equal(got[c], want), (k, bw, c)
+
+
+def test_q15_chain_197_bandwidths_without_recreating_the_chain(ctx, orc):
+    """Every bandwidth the menu can reach (100 < bw <= 5000 in steps of 25, UI.cpp:333-345), one block batch each, one chain."""
+    rng = np.random.default_rng(2)
+    ch, nt = 16, 102
+    lp, notch = _ref_nodes(orc)
+    bws = list(range(125, 5001, 25))
+    assert len(bws) == 196                                   # + the starting bandwidth = 197 settings
+    am = _am_taps(orc, nt, 2400)
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, am, am, mode=orclib.AM, biquad_nodes=[[lp], [notch]])
+    states = {c: {} for c in (0, 15)}
+    handle = chain.h.value
+    for k, bw in enumerate([2400] + bws):
+        if k:
+            am = _am_taps(orc, nt, bw)
+            chain.set_taps(0, am, am)
+        x = rng.integers(-20000, 20001, (ch, B)).astype(np.int16)
+        got = run_chain(ctx, chain, x, np.int16)
+        for c in states:
+            want = orc.chain_q15(x[c], orclib.AM, am, am, biquads=[orc.biquad_teensy_new([lp]), orc.biquad_teensy_new([notch])], state=states[c])
+            assert np.array_equal(got[c], want), (bw, c)
+    assert chain.h.value == handle
+
+
+@pytest.mark.parametrize("ch,block", [(64, None), (5, B)])
+def test_q15_chain_notch_retune_keeps_node_history(ctx, orc, ch, block):
+    """tune(): biquad2_dac.setNotch(0, pdb_freq_actual / 8 * CORR_FACT, 15) on a running graph (Minimal-SDR.ino:356); also a second
+    stage added to biquad1_dac mid-stream (setCoefficients(1, ..) chains through the flag bit, filter_biquad.cpp:88) and stage >= 4 ignored."""
+    rng = np.random.default_rng(3)
+    nt = 102
+    lp, notch = _ref_nodes(orc)
+    am = _am_taps(orc, nt, 2400)
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, am, am, mode=orclib.AM, biquad_nodes=[[lp], [notch]])
+    nodes = {c: [orc.biquad_teensy_new([lp]), orc.biquad_teensy_new([notch])] for c in (0, ch - 1)}
+    states = {c: {} for c in nodes}
+    plan = [None, (1, 0, orc.biquad_design(orclib.BQ_NOTCH, np.float32(2990.0 * CORR), 15.0)),
+            (1, 0, orc.biquad_design(orclib.BQ_NOTCH, np.float32(3011.5 * CORR), 15.0)),
+            (0, 1, orc.biquad_design(orclib.BQ_LOWPASS, np.float32(3000.0 * CORR), 0.7)),
+            (0, 7, lp)]
+    for k, step in enumerate(plan):
+        if step:
+            node, stage, coef = step
+            chain.set_node_coefficients(node, stage, coef)
+            for c in nodes:
+                recs = states[c].get("bq", nodes[c])
+                orc.lib.orc_biquad_teensy_set_coefficients(C.byref(recs[node]), C.c_uint32(stage), orclib._ptr(np.ascontiguousarray(coef, np.int32)))
+                states[c]["bq"] = recs
+        x = rng.integers(-20000, 20001, (ch, 4 * B)).astype(np.int16)
+        got = run_chain(ctx, chain, x, np.int16, block=block)
+        for c in nodes:
+            want = orc.chain_q15(x[c], orclib.AM, am, am, biquads=nodes[c], state=states[c])
+            assert np.array_equal(got[c], want), (k, c)
+    with pytest.raises(msdr.MsdrError):
+        chain.set_node_coefficients(2, 0, lp)                 # no such node
+    with pytest.raises(msdr.MsdrError):
+        chain.set_biquad_coeffs(np.zeros(5, np.float32))      # the fp32 cascade belongs to F32 chains
+
+
+@pytest.mark.parametrize("flags", [0, msdr.CHAIN_NO_MFMA])
+def test_q15_chain_oscillator_tables_rewritten(ctx, orc, flags):
+    """Osc_I_buffer_i / Osc_Q_buffer_i rewritten between two update() calls: fs/4 tables -> fs/8 -> a detuned table."""
+    rng = np.random.default_rng(4)
+    ch, nt = 9, 102
+    am = _am_taps(orc, nt, 2400)
+    k = np.arange(B)
+    tables = [(np.round(32767 * np.sin(2 * np.pi * k * c / B)).astype(np.int16), np.round(32767 * np.cos(2 * np.pi * k * c / B)).astype(np.int16)) for c in (32, 16, 5, 32)]
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, am, am, mixer=msdr.MIXER_NCO, mode=orclib.LSB, osc_i=tables[0][0], osc_q=tables[0][1], flags=flags)
+    states = {c: {} for c in range(ch)}
+    for j, (oi, oq) in enumerate(tables):
+        if j:
+            chain.set_osc(oi, oq)
+        x = rng.integers(-20000, 20001, (ch, 3 * B)).astype(np.int16)
+        got = run_chain(ctx, chain, x, np.int16)
+        for c in range(ch):
+            want = orc.chain_q15(x[c], orclib.LSB, am, am, mixer=1, osc_i=oi, osc_q=oq, state=states[c])
+            assert np.array_equal(got[c], want), (j, c)
+    fs4 = msdr.Chain(ctx, msdr.ARITH_Q15, 1, am, am)
+    with pytest.raises(msdr.MsdrError):
+        fs4.set_osc(tables[0][0], tables[0][1])                # the Fs/4 mixer has no tables
+
+
+# ------------------------------------------------------------------------------------------------ fp32 chain
+def _f32_lowpass(n, bw, fs=24000.0):
+    k = np.arange(n) - (n - 1) / 2.0
+    h = np.sinc(2 * bw / fs * k) * np.kaiser(n, 7.0)
+    return (h / h.sum()).astype(np.float32)
+
+
+@pytest.mark.parametrize("ntaps,stages,flags", [(256, 2, 0), (256, 1, 0), (100, 2, 0), (100, 2, msdr.CHAIN_NO_MFMA), (61, 4, 0), (24, 0, 0)])
+def test_f32_chain_bandwidth_change_under_running_stream(ctx, orc, ntaps, stages, flags):
+    """AM / LSB / USB channels on two tap sets; set 0 (the AM low-pass) is rewritten five times mid-stream, set 1 once.  Covers the
+    envelope tables with the cascade as matrix products (256 taps, 2 sections), the taps-in-registers kernel (256 taps, 1 section),
+    the SSB tables that carry the cascade's numerator (first-sample corrections), the vector-ALU kernels, 3-4 sections."""
+    rng = np.random.default_rng(ntaps + stages)
+    ch = 12
+    bq = _f32_biquads(orc, stages) if stages else None
+    hi, hq = _hilbert_pair(ntaps)
+    lo = _f32_lowpass(ntaps, 2400)
+    modes = np.array([orclib.AM, orclib.LSB, orclib.USB, orclib.AM, orclib.AM, orclib.LSB] * 2, np.int32)
+    tapsets = np.array([0, 1, 1, 0, 1, 0] * 2, np.int32)           # (an AM channel on the Hilbert pair and an LSB channel on the low-pass too)
+    sets_i, sets_q = [lo, hi], [lo.copy(), hq]
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, sets_i, sets_q, mixer=msdr.MIXER_FS4, modes=modes, tapsets=tapsets, biquad_coeffs=bq, flags=flags)
+    states = {c: {} for c in range(ch)}
+    for k, bw in enumerate([2400, 2425, 600, 5000, 3000, 2400]):
+        if k:
+            lo = _f32_lowpass(ntaps, bw)
+            sets_i[0], sets_q[0] = lo, lo.copy()
+            chain.set_taps(0, lo, lo)
+            if k == 3:
+                hi2, hq2 = _hilbert_pair(ntaps, fc=1500.0, bw=2400.0)
+                sets_i[1], sets_q[1] = hi2, hq2
+                chain.set_taps(1, hi2, hq2)
+        x = rng.integers(-12000, 12001, (ch, 1500 + 128 * k)).astype(np.int16)
+        got = run_chain(ctx, chain, x, np.float32, block=None if k % 2 else 700)
+        for c in range(ch):
+            want = orc.chain_f32(x[c], int(modes[c]), sets_i[tapsets[c]], sets_q[tapsets[c]], SIN4, COS4, bq, state=states[c])
+            assert rel_rms(got[c], want) < TOL, (k, bw, c, rel_rms(got[c], want))
+
+
+@pytest.mark.parametrize("stages,mode,flags", [(1, orclib.AM, 0), (2, orclib.AM, 0), (2, orclib.LSB, 0), (2, orclib.USB, msdr.CHAIN_NO_MFMA),
+                                               (3, orclib.AM, 0), (4, orclib.LSB, 0)])
+def test_f32_chain_notch_retune_keeps_cmsis_state(ctx, orc, stages, mode, flags):
+    """arm_biquad_cascade_df1_f32's pCoeffs rewritten between two calls, pState kept: the notch moved (the reference's tune()), then the
+    low-pass too.  The oracle keeps its CMSIS state record and is handed the new coefficients."""
+    rng = np.random.default_rng(10 * stages + mode)
+    ch, ntaps = 6, 100
+    hi, hq = _hilbert_pair(ntaps)
+    bq = _f32_biquads(orc, stages)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, hi, hq, mixer=msdr.MIXER_FS4, mode=mode, biquad_coeffs=bq, flags=flags)
+    states = {c: {} for c in range(ch)}
+
+    def sec(kind, f, q):
+        c = orc.biquad_design(kind, np.float32(f * CORR), q).astype(np.float64) / 2 ** 30
+        return np.array([c[0], c[1], c[2], -c[3], -c[4]], np.float32)
+
+    edits = [None, (min(1, stages - 1), sec(orclib.BQ_NOTCH, 2950.0, 15.0)), (0, sec(orclib.BQ_LOWPASS, 3600.0, 0.6)),
+             (stages - 1, sec(orclib.BQ_NOTCH, 3100.0, 8.0)), (0, sec(orclib.BQ_LOWPASS, 5400.0, 0.54))]
+    for k, e in enumerate(edits):
+        if e:
+            bq = bq.copy()
+            bq[e[0]] = e[1]
+            chain.set_biquad_coeffs(bq)
+        x = rng.integers(-12000, 12001, (ch, 1300 + 100 * k)).astype(np.int16)
+        got = run_chain(ctx, chain, x, np.float32)
+        for c in range(ch):
+            want = orc.chain_f32(x[c], mode, hi, hq, SIN4, COS4, bq, state=states[c])
+            assert rel_rms(got[c], want) < TOL, (k, c, rel_rms(got[c], want), chain.info()["kernel"])
+
+
+def test_f32_chain_cascade_change_across_the_two_evaluation_orders(ctx, orc):
+    """A well-conditioned cascade (block-parallel, inside the chain kernel) rewritten into one the library runs in CMSIS order behind
+    the kernel (two 300 Hz high-pass sections), and back: the state crosses the two bases both ways."""
+    rng = np.random.default_rng(21)
+    ch, ntaps = 4, 100
+    hi, hq = _hilbert_pair(ntaps)
+    good = _f32_biquads(orc, 2)
+
+    def sec(kind, f, q):
+        c = orc.biquad_design(kind, np.float32(f * CORR), q).astype(np.float64) / 2 ** 30
+        return np.array([c[0], c[1], c[2], -c[3], -c[4]], np.float32)
+
+    bad = np.stack([sec(orclib.BQ_HIGHPASS, 300.0, 0.7), sec(orclib.BQ_HIGHPASS, 300.0, 0.7)])
+    assert msdr.biquad_cascade_info(bad)[2] and not msdr.biquad_cascade_info(good)[2]
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, hi, hq, mixer=msdr.MIXER_FS4, mode=orclib.LSB, biquad_coeffs=good)
+    states = {c: {} for c in range(ch)}
+    for k, bq in enumerate([good, bad, bad * np.float32(1.0), good, bad]):
+        if k:
+            chain.set_biquad_coeffs(bq)
+        x = rng.integers(-12000, 12001, (ch, 2000)).astype(np.int16)
+        got = run_chain(ctx, chain, x, np.float32)
+        seq = "biquad_df1_seq_kernel" in chain.info()["kernel"]
+        assert seq == (bq is not good), (k, chain.info()["kernel"])
+        for c in range(ch):
+            want = orc.chain_f32(x[c], orclib.LSB, hi, hq, SIN4, COS4, bq, state=states[c])
+            assert rel_rms(got[c], want) < (2e-5 if seq else TOL), (k, c, rel_rms(got[c], want))
+
+
+@pytest.mark.parametrize("stages,mode", [(2, orclib.LSB), (0, orclib.USB), (2, orclib.AM)])
+def test_f32_chain_oscillator_tables_rewritten(ctx, orc, stages, mode):
+    """fp32 NCO tables rewritten mid-stream: a folded period-4 table -> period 8 -> a full-rate 128-periodic table -> back."""
+    rng = np.random.default_rng(30 + stages)
+    ch, ntaps = 5, 100
+    hi, hq = _hilbert_pair(ntaps)
+    bq = _f32_biquads(orc, stages) if stages else None
+    tabs = [_q15_nco(4, 1), _q15_nco(8, 1), _q15_nco(128, 5), _q15_nco(4, 1)]
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, hi, hq, mixer=msdr.MIXER_NCO, mode=mode, osc_i=tabs[0][0], osc_q=tabs[0][1], biquad_coeffs=bq)
+    states = {c: {} for c in range(ch)}
+    for j, (oi, oq) in enumerate(tabs):
+        if j:
+            chain.set_osc(oi, oq)
+        x = rng.integers(-12000, 12001, (ch, 1400 + 7 * j)).astype(np.int16)
+        got = run_chain(ctx, chain, x, np.float32)
+        for c in range(ch):
+            want = orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq, state=states[c])
+            assert rel_rms(got[c], want) < TOL, (j, c, rel_rms(got[c], want), chain.info()["kernel"])
+
+
+def test_f32_chain_updates_with_pll_channels(ctx, orc):
+    """Row f2 inside the fp32 chain (SYNCAM PLL) rides on an auxiliary chain and a post cascade: both follow a tap change and a
+    cascade change, the PLL's state untouched.  (LMS channels are left out here: the filter's leak control takes a decision per
+    sample, so it answers 1e-7 in front of it with up to 4e-3 behind it -- tests/test_gpu_chain_post.py checks it in two parts.)"""
+    from test_gpu_chain_post import _am_if
+    rng = np.random.default_rng(40)
+    ch, ntaps, seg = 4, 61, 6 * B
+    lo = _f32_lowpass(ntaps, 2800)
+    bq = _f32_biquads(orc, 2)
+    modes = np.array([orclib.SYNCAM, orclib.AM, orclib.SYNCAM, orclib.LSB], np.int32)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, lo, lo, mixer=msdr.MIXER_FS4, modes=modes, biquad_coeffs=bq, flags=msdr.CHAIN_SYNCAM_PLL)
+    xall = _am_if(rng, ch, 4 * seg, 35.0)
+    states = {c: {} for c in range(ch)}
+    for k in range(4):
+        if k == 1:
+            lo = _f32_lowpass(ntaps, 3300)
+            chain.set_taps(0, lo, lo)
+        if k == 2:
+            bq = bq.copy()
+            c30 = orc.biquad_design(orclib.BQ_NOTCH, np.float32(2900.0 * CORR), 15.0).astype(np.float64) / 2 ** 30
+            bq[1] = [c30[0], c30[1], c30[2], -c30[3], -c30[4]]
+            chain.set_biquad_coeffs(bq)
+        x = np.ascontiguousarray(xall[:, k * seg:(k + 1) * seg])
+        got = run_chain(ctx, chain, x, np.float32)
+        for c in range(ch):
+            want = orc.chain_f32(x[c], int(modes[c]), lo, lo, SIN4, COS4, bq, state=states[c], pll=bool(modes[c] == orclib.SYNCAM))
+            assert rel_rms(got[c], want) < TOL, (k, c, rel_rms(got[c], want))
+
+
+# ------------------------------------------------------------------------------------------------ stage mirrors and the CMSIS shim
+def test_fir_stage_coefficients_rewritten(ctx, orc):
+    rng = np.random.default_rng(50)
+    ch = 5
+    for nt in (102, 256):
+        a, b = _am_taps(orc, nt, 2400), _am_taps(orc, nt, 900)
+        f = msdr.FirQ15(ctx, a, ch)
+        x = rng.integers(-20000, 20001, (ch, 6 * B)).astype(np.int16)
+        got = np.empty_like(x)
+        for k in range(6):
+            if k == 2:
+                f.set_coeffs(b)
+            if k == 4:
+                f.set_coeffs(a)
+            dx, dy = ctx.to_device(x[:, k * B:(k + 1) * B]), ctx.array((ch, B), np.int16)
+            f.process(dx, dy, B)
+            got[:, k * B:(k + 1) * B] = dy.download()
+        for c in range(ch):
+            # the oracle with a kept state: arm_fir_fast_q15 over blocks, pCoeffs' CONTENTS swapped between blocks
+            coeffs = a.copy()
+            S, st = orclib.FirQ15(), np.zeros(nt + B, np.int16)
+            orc.lib.orc_fir_init_q15(C.byref(S), C.c_uint16(nt), orclib._ptr(coeffs), orclib._ptr(st), C.c_uint32(B))
+            want = np.empty(6 * B, np.int16)
+            for k in range(6):
+                if k == 2:
+                    coeffs[:] = b
+                if k == 4:
+                    coeffs[:] = a
+                src = np.ascontiguousarray(x[c, k * B:(k + 1) * B])
+                dst = np.empty(B, np.int16)
+                orc.lib.orc_fir_fast_q15(C.byref(S), orclib._ptr(src), orclib._ptr(dst), C.c_uint32(B))
+                want[k * B:(k + 1) * B] = dst
+            assert np.array_equal(got[c], want), (nt, c)
+    # fp32 stage: same plan, every kernel family (taps in registers, taps in LDS, vector ALU)
+    for nt in (256, 400, 9):
+        a, b = _f32_lowpass(nt, 2400), _f32_lowpass(nt, 700)
+        f = msdr.FirF32(ctx, a, ch)
+        x = rng.standard_normal((ch, 3 * 1500)).astype(np.float32)
+        got = np.empty_like(x)
+        for k, cf in enumerate([None, b, a]):
+            if cf is not None:
+                f.set_coeffs(cf)
+            dx, dy = ctx.to_device(x[:, 1500 * k:1500 * (k + 1)]), ctx.array((ch, 1500), np.float32)
+            f.process(dx, dy, 1500)
+            got[:, 1500 * k:1500 * (k + 1)] = dy.download()
+        for c in range(ch):
+            want = np.concatenate([np.convolve(x[c].astype(np.float64), cf.astype(np.float64)[::-1])[:x.shape[1]][1500 * k:1500 * (k + 1)] for k, cf in enumerate([a, b, a])])
+            assert rel_rms(got[c], want) < 2e-6, (nt, c, rel_rms(got[c], want))
+
+
+@pytest.mark.parametrize("stages", [1, 2, 4])
+def test_biquad_stage_coefficients_rewritten_keeps_cmsis_state(ctx, orc, stages):
+    rng = np.random.default_rng(60 + stages)
+    ch, n = 7, 1200
+    bqA = _f32_biquads(orc, stages)
+    bqB = bqA.copy()
+    c = orc.biquad_design(orclib.BQ_NOTCH if stages > 1 else orclib.BQ_LOWPASS, np.float32(2700.0 * CORR), 9.0 if stages > 1 else 0.8).astype(np.float64) / 2 ** 30
+    bqB[min(1, stages - 1)] = [c[0], c[1], c[2], -c[3], -c[4]]
+    f = msdr.BiquadDf1F32(ctx, bqA, ch)
+    x = rng.standard_normal((ch, 3 * n)).astype(np.float32)
+    got = np.empty_like(x)
+    for k, cf in enumerate([None, bqB, bqA]):
+        if cf is not None:
+            f.set_coeffs(cf)
+        dx, dy = ctx.to_device(x[:, n * k:n * (k + 1)]), ctx.array((ch, n), np.float32)
+        f.process(dx, dy, n)
+        got[:, n * k:n * (k + 1)] = dy.download()
+    for cidx in range(ch):
+        coeffs = bqA.reshape(-1).copy()
+        st = np.zeros(4 * stages, np.float32)
+        S = orclib.BiquadDf1()
+        orc.lib.orc_biquad_df1_init_f32(C.byref(S), C.c_uint8(stages), orclib._ptr(coeffs), orclib._ptr(st))
+        want = np.empty(3 * n, np.float32)
+        for k, cf in enumerate([bqA, bqB, bqA]):
+            coeffs[:] = cf.reshape(-1)
+            src, dst = np.ascontiguousarray(x[cidx, n * k:n * (k + 1)]), np.empty(n, np.float32)
+            orc.lib.orc_biquad_df1_f32_run(C.byref(S), orclib._ptr(src), orclib._ptr(dst), C.c_uint32(n))
+            want[n * k:n * (k + 1)] = dst
+        for k in range(3):
+            assert rel_rms(got[cidx, n * k:n * (k + 1)], want[n * k:n * (k + 1)]) < 5e-6, (stages, cidx, k)
+    assert np.abs(f.cmsis_state(0, stages)).max() > 0
+
+
+def test_cmsis_shim_follows_pcoeffs_rewritten_in_place(ctx, orc):
+    """The sketch's own calls: arm_fir_fast_q15(&FIR_I, ...) block after block while calc_demod_filter() rewrites FIR_AM_coeffs."""
+    lib = ctx.lib
+    rng = np.random.default_rng(70)
+    ch, nt = 3, 102
+
+    class FirInst(C.Structure):
+        _fields_ = [("numTaps", C.c_uint16), ("pState", C.c_void_p), ("pCoeffs", C.c_void_p)]
+
+    lib.msdr_cmsis_bind.argtypes = [C.c_void_p, C.c_uint32]
+    lib.msdr_arm_fir_init_q15.argtypes = [C.c_void_p, C.c_uint16, C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.msdr_arm_fir_fast_q15.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.msdr_arm_fir_fast_q15.restype = None
+    assert lib.msdr_cmsis_bind(ctx.h, ch) == 0
+    coeffs = _am_taps(orc, nt, 2400)
+    state = np.zeros(nt + B, np.int16)
+    inst = FirInst()
+    assert lib.msdr_arm_fir_init_q15(C.byref(inst), nt, orclib._ptr(coeffs), orclib._ptr(state), B) == 0
+    x = rng.integers(-20000, 20001, (ch, 6 * B)).astype(np.int16)
+    got = np.empty_like(x)
+    plan = {2: 900, 3: 925, 5: 4000}
+    wants = {c: [] for c in range(ch)}
+    oc = coeffs.copy()
+    oS = {c: (orclib.FirQ15(), np.zeros(nt + B, np.int16)) for c in range(ch)}
+    for c in range(ch):
+        orc.lib.orc_fir_init_q15(C.byref(oS[c][0]), C.c_uint16(nt), orclib._ptr(oc), orclib._ptr(oS[c][1]), C.c_uint32(B))
+    for k in range(6):
+        if k in plan:
+            coeffs[:] = _am_taps(orc, nt, plan[k])             # in place: same array, no init
+            oc[:] = coeffs
+        dx, dy = ctx.to_device(x[:, k * B:(k + 1) * B]), ctx.array((ch, B), np.int16)
+        lib.msdr_arm_fir_fast_q15(C.byref(inst), dx.ptr, dy.ptr, B)
+        got[:, k * B:(k + 1) * B] = dy.download()
+        for c in range(ch):
+            src, dst = np.ascontiguousarray(x[c, k * B:(k + 1) * B]), np.empty(B, np.int16)
+            orc.lib.orc_fir_fast_q15(C.byref(oS[c][0]), orclib._ptr(src), orclib._ptr(dst), C.c_uint32(B))
+            wants[c].append(dst)
+    for c in range(ch):
+        assert np.array_equal(got[c], np.concatenate(wants[c])), c
+    lib.msdr_cmsis_bind(None, 0)

@@ -367,7 +367,16 @@ typedef struct {
     /* IIR stage */
     float    in_scale;               /* F32: int16 -> float scale; 0 means 1/32768 (arm_q15_to_float) */
     uint32_t num_biquad_stages;      /* F32: 0..4 stages of arm_biquad_cascade_df1_f32 */
-    const float32_t *biquad_coeffs;  /* F32: host, 5*num_biquad_stages */
+    const float32_t *biquad_coeffs;  /* F32: host, 5*num_biquad_stages.  ACCURACY CONTRACT of the fp32 chain (tests/test_gpu_f32_contract.py):
+                                      *   every output row is within 1e-5 relative RMS of arm_fir_f32 + arm_biquad_cascade_df1_f32 evaluated in CMSIS order in
+                                      *   fp32 -- or, where that sequential fp32 evaluation is itself further than that from the exact (float64) result, within
+                                      *   TWICE its distance from the exact result (+ 1e-6).  The second clause matters for cascades whose sections ring
+                                      *   (narrow notches, resonant low / high-passes, three or more sections): their fp32 rounding noise, in any order of
+                                      *   evaluation, is msdr_biquad_df1_f32_cascade_info()'s *fp32_noise (4e-7 for the reference's LP + notch; 1e-5 and more for
+                                      *   random Q 8 sections below 1 kHz), and the block-parallel solver adds up to *kappa times the per-sample rounding; the
+                                      *   library switches to the CMSIS order itself (one lane per channel behind the main kernel, *cmsis_order = 1) when
+                                      *   kappa > 30 (20 from three sections on), kappa x fp32_noise > 2e-5 or fp32_noise > 2e-6, and for three or four sections
+                                      *   behind the general kernel.  With the reference's filters and all BASELINE configurations: 5-6e-7. */
     uint32_t num_biquad_nodes;       /* Q15: 0..2 AudioFilterBiquad nodes in series (biquad1_dac, biquad2_dac) */
     uint32_t node_stages[2];         /* Q15: stages used in each node (1..4) */
     const int32_t *node_coefs[2];    /* Q15: host, 5*node_stages[k] ints as given to setCoefficients */

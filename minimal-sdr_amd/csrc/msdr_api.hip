@@ -1948,6 +1948,8 @@ static void chain_free(msdr_chain *c)
 // floors for the state bounds of a chain that is being rebuilt under a running stream (chain_rebuild): the state the OLD tables left
 // behind must fit the new tables' fp16 intake too
 static thread_local double g_chain_floor_d = 0.0, g_chain_floor_sig = 0.0;
+// set while chain_create_impl re-creates a chain whose cascade must run in CMSIS order for a reason only the finished chain shows
+static thread_local bool g_chain_force_seq_cascade = false;
 
 static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_chain **out);
 extern "C" int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_chain **out)
@@ -1983,7 +1985,8 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
     if (!mode_ok(cfg->default_mode)) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad default_mode");
 
     if (f32 && cfg->num_biquad_stages &&
-        cascade_needs_cmsis_order(cfg->biquad_coeffs, (int)cfg->num_biquad_stages)) {
+        (g_chain_force_seq_cascade || cascade_needs_cmsis_order(cfg->biquad_coeffs, (int)cfg->num_biquad_stages))) {
+        g_chain_force_seq_cascade = false;
         // the parallel "numerators first" evaluation would lose accuracy on this cascade (cascade_condition): build the chain without
         // it and run arm_biquad_cascade_df1_f32 as written behind the main kernel (one lane per channel)
         msdr_chain_config plain = *cfg;
@@ -2596,6 +2599,17 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
     }
     if (!rc && !f32 && (cfg->flags & MSDR_CHAIN_SYNCAM_PLL)) rc = msdr_syncam_create(ctx, c->channels, &c->pll);
     if (rc) { chain_free(c); return rc; }
+    if (f32 && c->nstages >= 3 && !c->mf_ok && c->fold_P == 0) {
+        // Three or four sections behind chain_kernel<ArithF32> (no matrix-core tables, no folded tables: a long FIR behind a general
+        // oscillator table): the only place where the block-parallel cascade runs with 12-sample lanes, and the one configuration in
+        // round 3's fuzz records (profiles/r03/fuzz_kernels_606_final.txt: four sections, 1.07e-5) that no criterion excused.  The
+        // kernel is the slow fallback anyway: the cascade runs section by section in CMSIS order behind it.
+        chain_free(c);
+        g_chain_force_seq_cascade = true;
+        const int rc2 = chain_create_impl(ctx, cfg, out);
+        g_chain_force_seq_cascade = false;
+        return rc2;
+    }
     *out = c;
     return 0;
 }

@@ -1,0 +1,137 @@
+"""The fp32 chain's accuracy contract, as the gate sees it (include/msdr.h, next to msdr_chain_config.biquad_coeffs).
+
+The oracle is a sequential fp32 program (oracle/msdr_oracle.c: orc_chain_f32, CMSIS order).  Behind a cascade with resonant sections
+or deep stop bands ITS OWN rounding noise is a visible fraction of what is left of the signal: two correct fp32 evaluations then differ
+by more than 1e-5 of the output although each is as close to the exact result as fp32 allows.  With the reference's filters and every
+BASELINE configuration the library is at 5-6e-7 of the oracle; with RANDOM cascades of 1-4 sections about 3 % of the cases land
+between 1e-5 and 1e-4 of the oracle (1150 of 39 940 in profiles/r03/fuzz_truth_2026_final.txt).  The contract therefore reads
+
+        |gpu - oracle| <= 1e-5 |oracle|                                   or, where the oracle itself is that noisy,
+        |gpu - f64|    <= 2 |oracle - f64| + 1e-6 |f64|                   (f64: the same chain evaluated in float64, below)
+
+i.e. the library may be up to twice as far from the exact result as the CMSIS order is, never more.  This file asserts exactly that
+on fixed seeds -- the cases of tests/debug/fuzz_f32_truth.py (each draws from default_rng([seed, case])), including the ones the
+fuzzers flagged -- so the excusal is judged by the gate and not by a debug script."""
+import numpy as np
+import pytest
+from scipy.signal import lfilter
+
+import orclib
+from gpuhelp import ctx, msdr, rel_rms  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+B = 128
+
+
+def truth64(x, mode, hi, hq, oi, oq, bq):
+    """orc_chain_f32 with every operation in float64."""
+    n = np.arange(x.size)
+    xf = x.astype(np.float64) * (1.0 / 32768)
+    wi, wq = xf * oq.astype(np.float64)[n % oq.size], xf * oi.astype(np.float64)[n % oi.size]
+    ai = lfilter(hi.astype(np.float64)[::-1], [1.0], wi)
+    aq = lfilter(hq.astype(np.float64)[::-1], [1.0], wq)
+    d = ai - aq if mode == orclib.LSB else ai + aq if mode == orclib.USB else np.sqrt(ai * ai + aq * aq)
+    if bq is not None:
+        for c in np.asarray(bq, np.float64):
+            d = lfilter(c[:3], [1.0, -c[3], -c[4]], d)
+    return d
+
+
+def _case(orc, seed, case, q_max=8.0):
+    """One case of tests/debug/fuzz_f32_truth.py, draw for draw."""
+    rng = np.random.default_rng([seed, case])
+    ntaps = int(rng.integers(2, 300))
+    ch = int(rng.choice([1, 3, 40]))
+    n = int(rng.integers(2, 80)) * B
+    hi = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    hq = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    modes = rng.choice([orclib.AM, orclib.LSB, orclib.USB, orclib.CW], ch).astype(np.int32)
+    if rng.integers(0, 2):
+        hq = hi.copy()
+    mixer = int(rng.integers(0, 2))
+    P = int(rng.choice([1, 2, 4, 8, 16, 32, 64]))
+    k = np.arange(B)
+    if mixer:
+        oi = (np.round(32767 * np.sin(2 * np.pi * k / P)).astype(np.int16) / 32768.0).astype(np.float32)
+        oq = (np.round(32767 * np.cos(2 * np.pi * k / P)).astype(np.int16) / 32768.0).astype(np.float32)
+    else:
+        oi, oq = np.array([0, 1, 0, -1], np.float32)[k % 4], np.array([1, 0, -1, 0], np.float32)[k % 4]
+    stages = int(rng.integers(1, 5))
+    rows = []
+    for _ in range(stages):
+        kind = int(rng.choice([orclib.BQ_LOWPASS, orclib.BQ_NOTCH, orclib.BQ_HIGHPASS]))
+        c_ = orc.biquad_design(kind, np.float32(rng.uniform(800, 9000)), float(rng.uniform(0.5, q_max))).astype(np.float64) / 2 ** 30
+        rows.append([c_[0], c_[1], c_[2], -c_[3], -c_[4]])
+    bq = np.array(rows, np.float32)
+    kindx = rng.integers(0, 3)
+    x = (rng.integers(-32768, 32768, (ch, n)) if kindx == 0 else rng.integers(-300, 301, (ch, n)) if kindx == 1
+         else np.sign(rng.standard_normal((ch, n))) * 32767).astype(np.int16)
+    segs = int(rng.choice([0, 0, 1, 3]))
+    return dict(rng=rng, ntaps=ntaps, ch=ch, n=n, hi=hi, hq=hq, modes=modes, mixer=mixer, oi=oi, oq=oq, bq=bq, x=x, segs=segs, stages=stages)
+
+
+def _judge(ctx, orc, cs, tag, stats):
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, cs["ch"], cs["hi"], cs["hq"], mixer=cs["mixer"], modes=cs["modes"],
+                       osc_i=cs["oi"] if cs["mixer"] else None, osc_q=cs["oq"] if cs["mixer"] else None, biquad_coeffs=cs["bq"],
+                       time_segments=cs["segs"])
+    dx, dy = ctx.to_device(cs["x"]), ctx.array((cs["ch"], cs["n"]), np.float32)
+    chain.process(dx, dy, cs["n"])
+    got = dy.download()
+    kernel = chain.info()["kernel"]
+    for c in cs["rng"].choice(cs["ch"], min(cs["ch"], 3), replace=False):
+        want = orc.chain_f32(cs["x"][c], cs["modes"][c], cs["hi"], cs["hq"], cs["oi"], cs["oq"], cs["bq"])
+        e_go = rel_rms(got[c], want)
+        stats["checks"] += 1
+        if e_go < 1e-5:
+            continue
+        stats["over"] += 1
+        t = truth64(cs["x"][c], int(cs["modes"][c]), cs["hi"], cs["hq"], cs["oi"], cs["oq"], cs["bq"])
+        e_gpu, e_orc = rel_rms(got[c], t), rel_rms(want, t)
+        stats["worst"] = max(stats["worst"], e_gpu / max(e_orc, 1e-12))
+        assert e_gpu <= 2 * e_orc + 1e-6, (tag, int(c), kernel, "gpu-oracle %.2e gpu-f64 %.2e oracle-f64 %.2e" % (e_go, e_gpu, e_orc))
+    chain.close()
+
+
+def test_fp32_contract_on_the_fuzzers_cases(ctx, orc):
+    """Seed 2026: cases 1 .. 150 and the flagged 39938; seeds 88 and 911 (the other two recorded runs): cases 1 .. 25 each."""
+    stats = dict(checks=0, over=0, worst=0.0)
+    for seed, cases in ((2026, list(range(1, 151)) + [39938]), (88, range(1, 26)), (911, range(1, 26))):
+        for case in cases:
+            _judge(ctx, orc, _case(orc, seed, case), (seed, case), stats)
+    print("fp32 contract: %d channel checks, %d beyond 1e-5 of the fp32 oracle and judged against float64 (worst e_gpu / e_orc %.2f)"
+          % (stats["checks"], stats["over"], stats["worst"]))
+    assert stats["checks"] >= 200
+    assert stats["over"] >= 1, "no case exercised the float64 criterion: the seeds no longer reproduce the fuzzers' cases"
+
+
+def test_many_sections_behind_the_general_kernel_run_in_cmsis_order(ctx, orc):
+    """The one case of round 3's fuzz records that no criterion excused (profiles/r03/fuzz_kernels_606_final.txt: 277 taps behind a
+    128-periodic table, four sections, chain_kernel<ArithF32>, 1.07e-5): three or four sections behind the general kernel -- the only
+    place where the block-parallel cascade runs with 12-sample lanes -- now run section by section in CMSIS order."""
+    rng = np.random.default_rng(606)
+    k = np.arange(B)
+    oi = (np.round(32767 * np.sin(2 * np.pi * k / 128)).astype(np.int16) / 32768.0).astype(np.float32)
+    oq = (np.round(32767 * np.cos(2 * np.pi * k / 128)).astype(np.int16) / 32768.0).astype(np.float32)
+    for trial in range(12):
+        ntaps, stages = int(rng.integers(248, 300)), int(rng.integers(3, 5))
+        hi = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+        hq = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+        rows = []
+        for _ in range(stages):
+            kind = int(rng.choice([orclib.BQ_LOWPASS, orclib.BQ_NOTCH, orclib.BQ_HIGHPASS]))
+            c_ = orc.biquad_design(kind, np.float32(rng.uniform(800, 9000)), float(rng.uniform(0.5, 8))).astype(np.float64) / 2 ** 30
+            rows.append([c_[0], c_[1], c_[2], -c_[3], -c_[4]])
+        bq = np.array(rows, np.float32)
+        x = rng.integers(-32768, 32768, (3, 33 * B)).astype(np.int16)
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, 3, hi, hq, mixer=msdr.MIXER_NCO, mode=orclib.USB, osc_i=oi, osc_q=oq, biquad_coeffs=bq)
+        dx, dy = ctx.to_device(x), ctx.array(x.shape, np.float32)
+        chain.process(dx, dy, x.shape[1])
+        got = dy.download()
+        assert chain.info()["kernel"] == "chain_kernel<ArithF32> + biquad_df1_seq_kernel", chain.info()["kernel"]
+        for c in range(3):
+            want = orc.chain_f32(x[c], orclib.USB, hi, hq, oi, oq, bq)
+            e = rel_rms(got[c], want)
+            if e >= 1e-5:
+                t = truth64(x[c], orclib.USB, hi, hq, oi, oq, bq)
+                assert rel_rms(got[c], t) <= 2 * rel_rms(want, t) + 1e-6, (trial, c, e)
+        chain.close()

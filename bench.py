@@ -47,6 +47,50 @@ def ceiling_fracs(roofline):
     roofline["frac_of_measured_copy"] = round(a / MEASURED_COPY_GBS, 4)
     roofline["measured_copy_GBps"] = MEASURED_COPY_GBS
     return roofline
+def power_probe(step, torch, dev, device_index, world):
+    """Shader clock and socket power while the record's step loops UNTIMED (after the timed region): every matrix-core kernel of this
+    bench runs at the package's power cap, where time = energy / cap and the clock is whatever the cap leaves -- the figure that explains
+    a roofline fraction belongs next to it.  Three rocm-smi samples, ~0.3 s apart, taken while a helper thread keeps the queue fed.
+    Single-GPU runs only (rank 0 would otherwise hold the other ranks at the next barrier)."""
+    if world != 1:
+        return {"sclk_mhz": None, "power_w": None, "power_note": "sampled on single-GPU runs only"}
+    import re
+    import subprocess
+    import threading
+    stop = threading.Event()
+
+    def feed():
+        while not stop.is_set():
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize(dev)
+    th = threading.Thread(target=feed, daemon=True)
+    th.start()
+    time.sleep(0.6)
+    clocks, watts, err = [], [], None
+    for _ in range(3):
+        try:
+            txt = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                 text=True, timeout=20).stdout
+            m = re.search(r"sclk clock level:[^(]*\((\d+)Mhz\)", txt)
+            w = re.search(r"Socket[^:]*Power \(W\):\s*([0-9.]+)", txt)
+            if m:
+                clocks.append(int(m.group(1)))
+            if w:
+                watts.append(float(w.group(1)))
+        except (OSError, subprocess.SubprocessError) as e:
+            err = str(e)[:120]
+        time.sleep(0.3)
+    stop.set()
+    th.join()
+    torch.cuda.synchronize(dev)
+    out = {"sclk_mhz": int(np.median(clocks)) if clocks else None, "power_w": float(np.median(watts)) if watts else None,
+           "power_samples": {"sclk_mhz": clocks, "power_w": watts, "how": "rocm-smi --showclocks --showpower, 3 samples while the step loops untimed after the timed region"}}
+    if err and not clocks:
+        out["power_note"] = "rocm-smi unavailable: " + err
+    return out
+
+
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 matrix peak (same guide)
 
@@ -129,7 +173,7 @@ def synth_if(torch, dev, channels, n, seed):
 
 
 def pick_team(run, xs, modes, ts, limit):
-    """Size of the OpenMP team for the CPU leg: the smallest team whose rate is within 7 % of the best over a ladder of team sizes
+    """Size of the OpenMP team for the CPU leg: the team with the best rate over a ladder of team sizes
     up to `limit` (= usable_cores()), measured on a short weak-scaling sample (two rows of 2^16 samples per thread).  A lease that
     is a share of the machine -- by a quota this process cannot see -- shows up here as a rate that stops growing; the record's
     `cores` is the team that actually ran, never the machine's core count.  Returns (team, {team: Msamples/s})."""
@@ -145,7 +189,7 @@ def pick_team(run, xs, modes, ts, limit):
             best = max(best, rows * cols / dt)
         rates[t] = best
     top = max(rates.values())
-    team = min(t for t, r in rates.items() if r >= 0.93 * top)
+    team = min(t for t, r in rates.items() if r >= top)        # the team with the BEST rate (ties: the smaller one)
     return team, {str(t): round(r / 1e6, 2) for t, r in sorted(rates.items())}
 
 
@@ -206,7 +250,7 @@ def cpu_baseline(wl, x_host, gpu_first, target_s=12.0):
             "one_thread_Msamples_per_s": round(rate1 / 1e6, 3), "scaling_vs_one_thread": round(rate / (cores * rate1), 3),
             "team_ladder_Msamples_per_s": ladder,
             "sample": "%d row(s) x %d samples of the same IF input, %d pass(es), %.1f s wall (oracle/msdr_oracle.c orc_chain_f32; OpenMP team of %d = "
-                      "the smallest team within 7 %% of the best rate on this lease, see team_ladder)" % (xs.shape[0], per_row, passes, total_dt, cores)}, worst, min(per_row, gpu_first.shape[1])
+                      "the team with the best rate on this lease, see team_ladder)" % (xs.shape[0], per_row, passes, total_dt, cores)}, worst, min(per_row, gpu_first.shape[1])
 
 
 def cpu_baseline_q15(wl, x_host, gpu_first, target_s=12.0):
@@ -528,6 +572,10 @@ def bench_fir_stage(args, torch, msdr, ctx, dev, rank, world, dist, do_cpu):
     dt = timed_steps(args, torch, dev, dist, step, after_warmup=ctx.kernel_time)
     k_total, launches = ctx.kernel_time()
     ctx.enable_kernel_timing(False)
+    power = power_probe(step, torch, dev, dev.index or 0, world) if rank == 0 else None
+    x_cpu = None
+    if rank == 0 and do_cpu:                                     # rows of the same input for the timed CPU leg (two per thread of its team)
+        x_cpu = x[:min(ch, max(2 * usable_cores()[0], 16)), :min(n, 1 << 18)].cpu().numpy()
     fir.close()
     del x, y
     torch.cuda.empty_cache()
@@ -548,6 +596,8 @@ def bench_fir_stage(args, torch, msdr, ctx, dev, rank, world, dist, do_cpu):
                         "traffic": None, "kernel_ms": round(k_ms, 4), "launches_timed": int(launches),
                         "note": "%d B per sample; kernel_ms from HIP events around the stage's main kernel (its history kernel, ~6 us, is in ms_per_step only)" % int(bps)}}
     attach_traffic(out, "fir_q15" if q15 else "fir_f32", args)
+    if power:
+        out["roofline"].update(power)
     if do_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orclib
@@ -565,9 +615,36 @@ def bench_fir_stage(args, torch, msdr, ctx, dev, rank, world, dist, do_cpu):
                 want = orc.fir_f32_blocks(taps, xs[:m], 128)[skip:].astype(np.float64)
                 worst = max(worst, float(np.sqrt(((want - got[:want.size]) ** 2).sum() / max((want ** 2).sum(), 1e-300))))
             nsamp += xs.size
-        cdt = time.perf_counter() - t1
-        out["cpu_baseline"] = dict({"value": round(nsamp / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-                                    "sample": "%d windows of the same input incl. pre-roll, through ctypes (oracle/msdr_oracle.c)" % len(keep)}, **host_info())
+        # the timed CPU leg: the oracle's FIR over rows of the same input, an OpenMP team sized like the headline's (pick_team)
+        xs_all = np.ascontiguousarray(x_cpu if not q15 else x_cpu[:, :(x_cpu.shape[1] // 128) * 128])
+        ys_all = np.empty_like(xs_all)
+        tp = np.ascontiguousarray(taps)
+        fn_b = orc.lib.orc_fir_q15_batch if q15 else orc.lib.orc_fir_f32_batch
+        fn_b.argtypes = [C.c_void_p, C.c_uint16, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int]
+
+        def run(xs_, modes_, ts_, thr):
+            xs_ = np.ascontiguousarray(xs_)
+            t0 = time.perf_counter()
+            used = fn_b(tp.ctypes.data, C.c_uint16(nt), xs_.ctypes.data, ys_all.ctypes.data, C.c_uint32(xs_.shape[0]), C.c_uint64(xs_.shape[1]), C.c_uint32(128), int(thr))
+            return None, time.perf_counter() - t0, used
+        dummy = np.zeros(xs_all.shape[0], np.int32)
+        cal = xs_all[:1, :min(xs_all.shape[1], 1 << 17)]
+        _, dt1, _ = run(cal, dummy[:1], dummy[:1], 1)
+        team, ladder = pick_team(run, xs_all, dummy, dummy, usable_cores()[0])
+        total_dt, passes, used = 0.0, 0, 1
+        while total_dt < 8.0 and passes < 5000:
+            _, dtp, used = run(xs_all, dummy, dummy, team)
+            total_dt += dtp
+            passes += 1
+        cores = int(min(used, xs_all.shape[0]))
+        rate, rate1 = xs_all.size * passes / total_dt, cal.size / dt1
+        out["cpu_baseline"] = dict({"value": round(rate / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                                    "one_thread_Msamples_per_s": round(rate1 / 1e6, 3), "scaling_vs_one_thread": round(rate / (cores * rate1), 3),
+                                    "team_ladder_Msamples_per_s": ladder,
+                                    "sample": "%d rows x %d samples of the same input, %d pass(es), %.1f s wall (oracle/msdr_oracle.c orc_fir_%s_batch: %s in "
+                                              "128-sample calls; OpenMP team of %d = the best rate on this lease)"
+                                              % (xs_all.shape[0], xs_all.shape[1], passes, total_dt, "q15" if q15 else "f32", "arm_fir_fast_q15" if q15 else "arm_fir_f32", cores)},
+                                   **host_info())
         out["parity"] = {("mismatching_samples" if q15 else "rel_rms_worst"): float("%.3g" % worst), "tolerance": 0 if q15 else 1e-6,
                          "windows": [{"channel": int(r), "start": int(lo), "length": int(L)} for (r, lo) in keep]}
     ceiling_fracs(out["roofline"])
@@ -596,7 +673,7 @@ def attach_traffic(out, tag, args):
             or args.time_segments or args.osc_period != 4 or any(k.startswith("MSDR_") and k not in ("MSDR_LIB", "MSDR_BENCH_REHEARSAL") for k in os.environ)):
         return
     ran = str(out["config"].get("kernel", "")).split("<")[0].split(" ")[0]
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         prof = os.path.join(ROOT, "profiles", rnd, "%s_rocprof_summary.txt" % tag)
         if not os.path.exists(prof):
             continue
@@ -741,6 +818,7 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
     dt = timed_steps(args, torch, dev, dist, lambda: chain.process(x.data_ptr(), y.data_ptr(), n), after_warmup=chain.kernel_time)
     kernel_ms, launches = chain.kernel_time()
     chain.enable_timing(False)
+    power = power_probe(lambda: chain.process(x.data_ptr(), y.data_ptr(), n), torch, dev, dev.index or 0, world) if rank == 0 else None
     if captured is not None:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orclib
@@ -891,6 +969,13 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
         r["mfma_i8_peak_tops"] = 2 * MFMA_F16_PEAK_TFLOPS
         r["note"] = "kernel_ms / achieved are the FIR + demod kernel (4 B/sample); the step also runs the Teensy biquad nodes (serial per channel)"
     attach_traffic(out, ("q15_" if q15 else "") + name, args)
+    if power:
+        out["roofline"].update(power)
+    if q15 and len(wl["bq"]):
+        # the as-written step = the FIR + demod kernel, then the two Teensy biquad nodes in place on the audio (serial per channel)
+        out["roofline"]["step_ms"] = round(dt / args.steps * 1e3, 4)
+        out["roofline"]["demod_kernel_ms"] = round(k_ms, 4)
+        out["roofline"]["node_pass_ms"] = round(dt / args.steps * 1e3 - k_ms, 4)
     if gather:
         out["gather"] = gather
     if do_cpu:
@@ -1027,14 +1112,25 @@ def main():
             also[name] = bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, False, False)   # parity windows, no timed CPU leg
             if also[name] is not None:
                 also[name]["warmup_steps_run"] = args.warmup_steps_run
+        if args.arith == "f32":
+            # the reference AS WRITTEN on the headline shape: arm_fir_fast_q15 pair + integer demod (bit-exact, i8 matrix cores), then
+            # biquad1_dac / biquad2_dac (Teensy Q2.30 biquads with error feedback: one lane per channel, latency-bound by construction)
+            args.arith = "q15"
+            also["q15_c3"] = bench_chain(args, "c3", torch, msdr, ctx, dev, rank, world, dist, False, False)
+            args.arith = "f32"
+            if also["q15_c3"] is not None:
+                also["q15_c3"]["warmup_steps_run"] = args.warmup_steps_run
         args.min_warm_s = 0.0
         if rank == 0:
             for k, rec in also.items():
                 for drop in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "data"):
                     rec.pop(drop, None)
             out["also"] = also
-            out["config"]["records"] = "headline = c3 (BASELINE.json configs[2]); also: fir (256-tap fp32 FIR stage alone), c2, c4, c5 -- each timed over the same K steps; their warm-up is W steps plus 0.2 s of untimed steps (warmup_steps_run), so that short steps are not timed on a card still climbing from its idle clock"
+            out["config"]["records"] = "headline = c3 (BASELINE.json configs[2]); also: fir (256-tap fp32 FIR stage alone), c2, c4, c5, q15_c3 (c3 through the reference's own integer arithmetic, bit-exact) -- each timed over the same K steps; their warm-up is W steps plus 0.2 s of untimed steps (warmup_steps_run), so that short steps are not timed on a card still climbing from its idle clock"
     if rank == 0:
+        import ctypes as C
+        ctx.lib.msdr_build_rev.restype = C.c_char_p
+        out["library_rev"] = ctx.lib.msdr_build_rev().decode()       # the source revision lib/libmsdr.so was built from
         out["n_ranks_seen"] = dist.get_world_size() if dist is not None else 1
         out["rank_devices"] = args.rank_devices
         if rehearsal:

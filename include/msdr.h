@@ -81,6 +81,7 @@ int  msdr_ctx_synchronize(msdr_ctx *ctx);
 void *msdr_ctx_stream(msdr_ctx *ctx);                       /* the hipStream_t in use */
 const char *msdr_last_error(void);                          /* thread-local text of the last failure */
 const char *msdr_version(void);
+const char *msdr_build_rev(void);                           /* source revision the library was built from ("<git hash>[+dirty]"), for measurement records */
 int  msdr_device_count(void);                               /* usable gfx950 devices; never initialises one */
 
 /* device-memory helpers (callers may equally pass pointers from hipMalloc or a torch tensor) */

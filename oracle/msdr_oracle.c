@@ -3,8 +3,12 @@
  *
  * TEST INFRASTRUCTURE, NOT PRODUCT (see msdr_oracle.h for who may load it and for the
  * pinned / "parity unpinned" status of every function).  Written from the reference's
- * arithmetic contract, not transcribed from its code: each function is the
- * per-sample formula the cited lines implement.  Build: oracle/Makefile
+ * arithmetic contract: most functions are the per-sample formula the cited lines
+ * implement, in this file's own words.  Two parts necessarily follow the sketch statement by statement,
+ * because their results depend on its order of float operations and must match it bit for bit -- the tap
+ * designer (orc_calc_fir_coeffs / orc_m_sinc / orc_izero after Minimal-SDR.ino:782-899) and the LMS filter's
+ * update (after Minimal-SDR.ino:702-770): about twenty lines there are close to the sketch's own.
+ * Build: oracle/Makefile
  * (gcc -O2 -ffp-contract=off -fwrapv -fno-strict-aliasing [-fopenmp]).
  */
 #include "msdr_oracle.h"
@@ -619,6 +623,49 @@ int orc_chain_f32_batch(const orc_chain_f32_cfg *cfg, const int32_t *mode_per_ch
         st.n0 = 0;
         orc_chain_f32(&lc, &st, x + (size_t)c * n, audio + (size_t)c * n, n);
         free(st.hist_i); free(st.hist_q);
+    }
+    return used;
+}
+
+/* The FIR stage alone over a block batch, fresh zero state per row, `block` samples per call (CMSIS cadence): the timed CPU
+ * baseline of bench.py's FIR record, on the same OpenMP team logic as the chain drivers. */
+int orc_fir_f32_batch(const float *coeffs, uint16_t num_taps, const float *x, float *y, uint32_t channels,
+                      uint64_t n, uint32_t block, int threads)
+{
+    int used = 1;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    used = threads > 0 ? threads : omp_get_max_threads();
+#endif
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < (int64_t)channels; c++) {
+        float *st = (float *)calloc((size_t)num_taps + block, sizeof(float));
+        orc_fir_instance_f32 S;
+        orc_fir_init_f32(&S, num_taps, coeffs, st, block);
+        for (uint64_t o = 0; o < n; o += block) {
+            const uint32_t m = (uint32_t)((n - o < block) ? (n - o) : block);
+            orc_fir_f32(&S, x + (size_t)c * n + o, y + (size_t)c * n + o, m);
+        }
+        free(st);
+    }
+    return used;
+}
+int orc_fir_q15_batch(const q15_t *coeffs, uint16_t num_taps, const q15_t *x, q15_t *y, uint32_t channels,
+                      uint64_t n, uint32_t block, int threads)
+{
+    int used = 1;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    used = threads > 0 ? threads : omp_get_max_threads();
+#endif
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < (int64_t)channels; c++) {
+        q15_t *st = (q15_t *)calloc((size_t)num_taps + block, sizeof(q15_t));
+        orc_fir_instance_q15 S;
+        if (orc_fir_init_q15(&S, num_taps, coeffs, st, block) == 0)
+            for (uint64_t o = 0; o + block <= n; o += block)
+                orc_fir_fast_q15(&S, x + (size_t)c * n + o, y + (size_t)c * n + o, block);
+        free(st);
     }
     return used;
 }

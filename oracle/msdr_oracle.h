@@ -159,6 +159,11 @@ void orc_chain_f32(const orc_chain_f32_cfg *cfg, orc_chain_f32_state *st, const 
 int orc_chain_f32_batch(const orc_chain_f32_cfg *cfg, const int32_t *mode_per_channel,
                         const int16_t *x, float *audio, uint32_t channels, uint64_t n,
                         int threads);
+/* FIR stage over a block batch (fresh zero state per row, `block` samples per call); return the OpenMP team size used */
+int orc_fir_f32_batch(const float *coeffs, uint16_t num_taps, const float *x, float *y, uint32_t channels,
+                      uint64_t n, uint32_t block, int threads);
+int orc_fir_q15_batch(const q15_t *coeffs, uint16_t num_taps, const q15_t *x, q15_t *y, uint32_t channels,
+                      uint64_t n, uint32_t block, int threads);
 int orc_chain_q15_batch(const orc_chain_q15_cfg *cfg, const int32_t *mode_per_channel,
                         const int16_t *x, int16_t *audio, uint32_t channels,
                         uint32_t n_blocks, int threads);

@@ -166,6 +166,9 @@ int msdr_fir_q15_destroy(msdr_fir_q15 *S);
 /* arm_fir_init_f32 / arm_fir_f32 (prototypes arm_math.h:1182-1202; CMSIS-DSP V1.5.x). Any numTaps >= 1. */
 typedef struct msdr_fir_f32 msdr_fir_f32;
 int msdr_fir_f32_create(msdr_ctx *ctx, uint16_t numTaps, const float32_t *pCoeffs, uint32_t channels, msdr_fir_f32 **out);
+/* (Not capturable into a HIP graph: the 16..~290-tap kernel deals its tiles from one of two counter sets that alternate between
+ * launches on the host, so a replayed launch would find its counters spent.  msdr_fir_f32_kernel_name reports the kernel for blocks
+ * below 2^31 tiles x channels; beyond that the one-stream-per-wave kernel runs.) */
 int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, float32_t *d_dst, uint32_t blockSize);
 int msdr_fir_f32_reset(msdr_fir_f32 *S);
 int msdr_fir_f32_set_coeffs(msdr_fir_f32 *S, const float32_t *pCoeffs);   /* as msdr_fir_q15_set_coeffs: state kept, same numTaps */
@@ -390,6 +393,9 @@ typedef struct {
     uint32_t flags;                  /* MSDR_CHAIN_* */
 } msdr_chain_config;
 #define MSDR_CHAIN_NO_TAP_FOLDING 1u /* F32: keep mixer and FIR pair as separate arithmetic steps (as written) */
+#define MSDR_CHAIN_NO_FFT 4u         /* deprecated, accepted and ignored (round 2's FFT kernel is gone) */
+#define MSDR_CHAIN_MFMA_WG 16u       /* deprecated, accepted and ignored (round 2's workgroup-tile matrix-core kernel is gone) */
+/* any other bit in msdr_chain_config.flags is refused with MSDR_STATUS_ARGUMENT_ERROR */
 #define MSDR_CHAIN_NO_MFMA 8u        /* never run the FIR on the matrix cores (F32: split-fp16 MFMA kernel; Q15: byte-split i8 MFMA kernel) */
 #define MSDR_CHAIN_FOLD_ANY_PERIOD 64u /* F32, NCO: fold the mixer into the taps (matrix-core kernel) also when the oscillator table's only period is its
                                          own length (8, 16 or 32 samples); a table that repeats within its length with period 1 .. 32 is folded by default */

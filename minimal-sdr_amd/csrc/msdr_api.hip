@@ -1983,6 +1983,10 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
     if (!f32 && cfg->num_biquad_nodes > 2) return fail(MSDR_STATUS_ARGUMENT_ERROR, "num_biquad_nodes > 2");
     auto mode_ok = [](int m) { return m >= MSDR_MODE_SYNCAM && m <= MSDR_MODE_CW; };
     if (!mode_ok(cfg->default_mode)) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad default_mode");
+    {
+        const uint32_t known = MSDR_CHAIN_NO_TAP_FOLDING | MSDR_CHAIN_NO_FFT | MSDR_CHAIN_NO_MFMA | MSDR_CHAIN_MFMA_WG | MSDR_CHAIN_SYNCAM_PLL | MSDR_CHAIN_FOLD_ANY_PERIOD;
+        if (cfg->flags & ~known) return fail(MSDR_STATUS_ARGUMENT_ERROR, "unknown bits 0x%x in msdr_chain_config.flags", cfg->flags & ~known);
+    }
 
     if (f32 && cfg->num_biquad_stages &&
         (g_chain_force_seq_cascade || cascade_needs_cmsis_order(cfg->biquad_coeffs, (int)cfg->num_biquad_stages))) {

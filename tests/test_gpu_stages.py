@@ -453,10 +453,11 @@ def test_fir_f32_isolated_spike(ctx, orc):
     """One 1e6 sample in a unit-variance row (arm_fir_f32 itself has no input-dependent precision, arm_math.h:1182-1186): the quiet
     outputs BEFORE the spike -- whose causal windows do not hold it, though the tile's block-floating-point scale does -- and the
     outputs more than N after it must keep 1e-5 relative RMS; the stretch the spike dominates is judged as a whole.  The bound the
-    library states in include/msdr.h (msdr_fir_f32_process): a sample 2^-R below the largest magnitude of its 1024-output tile's window
-    keeps 22 - max(0, R - 9) significant bits, so R = 20 (this test) leaves 2^-11 per SAMPLE of such a tile, and the outputs, sums of
-    256 such terms against taps of either sign, stay three orders of magnitude below 1e-5 of the row's level only where the spike is
-    in the window; before and after it they are relative to the quiet level."""
+    library states in include/msdr.h (msdr_fir_f32_set_input_range): every sample x of a tile's window enters the products with an error
+    of at most max(2^-21 |x|, 2^-39 Mw), Mw the window's largest magnitude -- full 22 bits down to 2^-18 of Mw, 22 - (R - 18) bits at
+    2^-R.  Here R = 20 (1e6 against unit variance): the quiet samples of the spike's own tile window keep 20 bits, an absolute error of
+    2^-39 x 1e6 = 1.8e-6 each, which is what the 1e-5 bound on the quiet stretches of that tile allows for; tiles whose window does
+    not hold the spike are untouched."""
     rng = np.random.default_rng(77)
     ntaps, ch, n = 256, 8, 6 * 1024
     h = (np.sinc(0.23 * (np.arange(ntaps) - 127.5)) * np.kaiser(ntaps, 7.0)).astype(np.float32)

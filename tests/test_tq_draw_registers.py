@@ -3,7 +3,10 @@ a vector register some time AFTER the instruction issued; the kernel reads that 
 knows nothing of this, so a copy or a reuse of the register between the draw and its take would read it too early.  This test
 disassembles the PRODUCT binary (lib/libmsdr.so, gfx950 code object) and checks, for every instantiation of the kernel, that between
 each `global_atomic_add vD ... sc0` and the `v_readfirstlane_b32 sX, vD` that takes it no instruction touches vD, and that the take
-follows an `s_waitcnt vmcnt(N)`.  No GPU needed."""
+follows an `s_waitcnt vmcnt(N)`.  It also checks the wait's ARITHMETIC: vmcnt(N) proves the draw has returned only if at least N vector-
+memory instructions were issued behind it (the counter retires in issue order), so on EVERY path from the atomic to its take the number
+of global / scratch / buffer / flat loads, stores and atomics must be >= N -- a compiler that merged, predicated away or dropped one of
+the stores or loads the kernel counts on would otherwise let the take read a stale register.  No GPU needed."""
 import os
 import re
 import shutil
@@ -95,5 +98,22 @@ def test_no_instruction_touches_a_pending_draw(tmp_path):
                 assert nxt or takes, "%s: a path from draw %r ends without taking it" % (kname, t)
                 stack.extend(nxt)
             assert takes >= 1, (kname, t)
+            # shortest path (in vector-memory instructions) from the draw to each of its takes: must cover the take's vmcnt(N)
+            import heapq
+            dist, heap = {i + 1: 0}, [(0, i + 1)]
+            while heap:
+                dj, j = heapq.heappop(heap)
+                if dj > dist.get(j, 1 << 30):
+                    continue
+                tj = ins[j][1]
+                if touches(tj, num):                                # a take (checked above): compare with its wait
+                    n_wait = int(re.match(r"s_waitcnt vmcnt\((\d+)\)", ins[j - 1][1]).group(1))
+                    assert dj >= n_wait, "%s: a path from %r reaches its take behind only %d vector-memory instructions, but the take waits for vmcnt(%d)" % (kname, t, dj, n_wait)
+                    continue
+                w = 1 if re.match(r"(global|scratch|buffer|flat)_(load|store|atomic)", tj) else 0
+                for nx in successors(j):
+                    if dj + w < dist.get(nx, 1 << 30):
+                        dist[nx] = dj + w
+                        heapq.heappush(heap, (dj + w, nx))
             draws += 1
     assert draws >= 4 * len(kernels)                             # three synchronous draws, one per slow iteration, one per fast iteration

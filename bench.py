@@ -669,7 +669,7 @@ def attach_traffic(out, tag, args):
     WRITE_SIZE x 1024, corrected as MI355X_MICROARCH.md prescribes).  It is attached only when the profile was taken on the kernel
     THIS run launched (names compared) and the run is the named configuration: any shape override, experiment switch or MSDR_*
     kernel-selection variable leaves `traffic` null."""
-    if (args.samples or args.channels or args.taps or args.stages >= 0 or args.no_mfma or args.no_fold
+    if (args.samples or args.channels or args.taps or args.stages >= 0 or args.no_mfma or args.no_fold or getattr(args, "out_i16", False)
             or args.time_segments or args.osc_period != 4 or any(k.startswith("MSDR_") and k not in ("MSDR_LIB", "MSDR_BENCH_REHEARSAL") for k in os.environ)):
         return
     ran = str(out["config"].get("kernel", "")).split("<")[0].split(" ")[0]
@@ -729,7 +729,7 @@ def chain_parity_capture(wl, info, x, y, q15, torch):
     return cap, L, bounds, preroll
 
 
-def chain_parity(wl, captured, q15, orc, orclib):
+def chain_parity(wl, captured, q15, orc, orclib, out_i16=False):
     """GPU output against the oracle on parity_windows(); the oracle runs over [lo - preroll, lo + L) restarted on an oscillator
     period boundary (FIR history and IIR state settle inside the pre-roll) -- tests/test_gpu_fullsize.py:_window_check."""
     cap, L, bounds, preroll = captured
@@ -746,10 +746,17 @@ def chain_parity(wl, captured, q15, orc, orclib):
             want = orc.chain_q15(xs[:m], mode, wl["qi"][ts], wl["qq"][ts], mixer=1 if oi is not None else 0, osc_i=oi, osc_q=oq,
                                  biquads=nodes)[lo - start:]
             worst = max(worst, float((want != got[:want.size]).sum()))
+        elif out_i16:      # the oracle's fp32 audio converted as arm_float_to_q15 does (truncate toward zero, saturate): at most 1 LSB apart
+            wf = orc.chain_f32(xs, mode, wl["ci"][ts], wl["cq"][ts], osc_i, osc_q, wl["bq"] if len(wl["bq"]) else None)[lo - start:]
+            want = np.clip(np.trunc((wf * np.float32(32768.0)).astype(np.float64)), -32768, 32767).astype(np.int32)
+            worst = max(worst, float(np.abs(want - got.astype(np.int32)).max()))
         else:
             want = orc.chain_f32(xs, mode, wl["ci"][ts], wl["cq"][ts], osc_i, osc_q, wl["bq"] if len(wl["bq"]) else None)[lo - start:].astype(np.float64)
             worst = max(worst, float(np.sqrt(((want - got) ** 2).sum() / max((want ** 2).sum(), 1e-300))))
         checked += L
+    if out_i16 and not q15:
+        return {"max_abs_lsb": float(worst), "tolerance": 1, "windows": [{"channel": int(c), "start": int(lo), "length": int(L)} for c, lo, _, _, _ in cap],
+                "segment_boundaries_covered": [int(b) for b in bounds], "oracle_preroll": preroll, "samples_checked": int(checked)}
     return {("mismatching_samples" if q15 else "rel_rms_worst"): float("%.3g" % worst), "tolerance": 0 if q15 else 1e-5,
             "windows": [{"channel": int(c), "start": int(lo), "length": int(L)} for c, lo, _, _, _ in cap],
             "segment_boundaries_covered": [int(b) for b in bounds], "oracle_preroll": preroll, "samples_checked": int(checked)}
@@ -780,6 +787,7 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
         wl["name"] += " [experiment: %d taps]" % args.taps
     ch, n = wl["channels"], wl["n"]
     q15 = args.arith == "q15"
+    i16 = bool(getattr(args, "out_i16", False)) and not q15     # fp32 chain, int16 audio out (MSDR_CHAIN_OUT_I16): 4 B per sample
     if q15:       # the same workload through the as-written integer chain: Q15 taps / oscillator, Teensy biquad nodes
         corr = msdr.AUDIO_SAMPLE_RATE_EXACT / FS
         wl["qi"] = [np.round(np.asarray(c, np.float64) * 32767).astype(np.int16) for c in wl["ci"]]
@@ -795,9 +803,9 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
                            tapsets=wl["tapsets"], osc_i=wl["osc"][0] if wl["osc"] else None, osc_q=wl["osc"][1] if wl["osc"] else None,
                            biquad_coeffs=wl["bq"] if len(wl["bq"]) else None, time_segments=args.time_segments,
                            flags=(msdr.CHAIN_NO_TAP_FOLDING if args.no_fold else 0)
-                           | (msdr.CHAIN_NO_MFMA if args.no_mfma else 0))
+                           | (msdr.CHAIN_NO_MFMA if args.no_mfma else 0) | (msdr.CHAIN_OUT_I16 if i16 else 0))
     x = synth_if(torch, dev, ch, n, wl["seed"])
-    y = torch.empty((ch, n), dtype=torch.int16 if q15 else torch.float32, device=dev)
+    y = torch.empty((ch, n), dtype=torch.int16 if (q15 or i16) else torch.float32, device=dev)
     torch.cuda.synchronize(dev)
 
     # first pass from zero state: kept for the parity checks (the timed passes continue the stream, state carried)
@@ -822,7 +830,7 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
     if captured is not None:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orclib
-        parity = chain_parity(wl, captured, q15, orclib.Oracle(), orclib)
+        parity = chain_parity(wl, captured, q15, orclib.Oracle(), orclib, out_i16=i16)
         if gpu_first is not None:
             gpu_first = gpu_first.cpu().numpy()
 
@@ -924,7 +932,7 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
     samples_per_step = ch * n
     value = world * samples_per_step * args.steps / dt / 1e6
     k_ms = kernel_ms / max(launches, 1)
-    alg_bytes = (4.0 if q15 else 6.0) * samples_per_step        # int16 in + fp32 (or int16) out
+    alg_bytes = (4.0 if (q15 or i16) else 6.0) * samples_per_step        # int16 in + fp32 (or int16) out
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     extra = (6 if wl["mixer"] == msdr.MIXER_NCO else 0) + 4 + 9 * len(wl["bq"])
     flop_written = 4.0 * wl["taps"] + extra                      # as the reference writes it: two N-tap FIRs
@@ -937,7 +945,7 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
         "dtype": "q15 (int16 data, wrapping int32 accumulate)" if q15 else "f32 (fp32 accumulate; matrix-core operands as 2 x fp16 pieces: int16 samples exact, taps 22 bits)",
         "data": "synthetic",
         "config": {"workload": wl["name"], "channels_per_gpu": ch, "samples_per_channel_per_step": n, "taps": wl["taps"],
-                   "biquad_stages": int(len(wl["bq"])), "in": "int16", "out": "int16" if q15 else "fp32", "sharding": "independent channels per GPU, no data-path collective",
+                   "biquad_stages": int(len(wl["bq"])), "in": "int16", "out": "int16" if (q15 or i16) else "fp32", "sharding": "independent channels per GPU, no data-path collective",
                    "kernel": info["kernel"], "grid": info["grid"], "time_segments": info["time_segments"], "iir_warmup": info["warmup"],
                    "tap_folding": not args.no_fold},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1036,6 +1044,7 @@ def main():
     ap.add_argument("--time-segments", type=int, default=0)
     ap.add_argument("--arith", default="f32", choices=["f32", "q15"],
                     help="f32 = the north-star flavour (default); q15 = the reference as written (int16 out, bit-exact)")
+    ap.add_argument("--out-i16", action="store_true", help="f32 arithmetic, int16 audio out (MSDR_CHAIN_OUT_I16, arm_float_to_q15): 4 B per sample instead of 6")
     ap.add_argument("--osc-period", type=int, default=4, help="experiment: NCO period in samples (4 = fs/4, the named config)")
     ap.add_argument("--stages", type=int, default=-1, help="experiment: override the number of biquad stages (0..2)")
     ap.add_argument("--taps", type=int, default=0, help="experiment: override the tap count (same designer)")
@@ -1118,6 +1127,12 @@ def main():
             args.arith = "q15"
             also["q15_c3"] = bench_chain(args, "c3", torch, msdr, ctx, dev, rank, world, dist, False, False)
             args.arith = "f32"
+            # the headline with int16 audio out (the play queue's type): the same arithmetic, 4 B per sample through HBM instead of 6
+            args.out_i16 = True
+            also["c3_i16"] = bench_chain(args, "c3", torch, msdr, ctx, dev, rank, world, dist, False, False)
+            args.out_i16 = False
+            if also["c3_i16"] is not None:
+                also["c3_i16"]["warmup_steps_run"] = args.warmup_steps_run
             if also["q15_c3"] is not None:
                 also["q15_c3"]["warmup_steps_run"] = args.warmup_steps_run
         args.min_warm_s = 0.0

@@ -395,6 +395,11 @@ typedef struct {
 #define MSDR_CHAIN_NO_TAP_FOLDING 1u /* F32: keep mixer and FIR pair as separate arithmetic steps (as written) */
 #define MSDR_CHAIN_NO_FFT 4u         /* deprecated, accepted and ignored (round 2's FFT kernel is gone) */
 #define MSDR_CHAIN_MFMA_WG 16u       /* deprecated, accepted and ignored (round 2's workgroup-tile matrix-core kernel is gone) */
+#define MSDR_CHAIN_OUT_I16 128u      /* F32: d_audio is int16 [channels][n_samples] -- the play queue's sample type (src/Audio/play_queue.h:41) -- written as
+                                        arm_float_to_q15 converts (prototype arm_math.h:6592; CMSIS-DSP 1.5.x: (q15_t) __SSAT((q31_t)(x * 32768.0f), 16)): 4 B
+                                        per sample through HBM instead of 6, and half the bytes in the audio gather.  The matrix-core kernels convert in
+                                        their store phase; chains that run a pass behind the main kernel (CMSIS-order cascade, PLL / LMS channels) or
+                                        one of the vector-ALU kernels go through an fp32 scratch block batch owned by the chain.  Ignored by Q15 chains. */
 /* any other bit in msdr_chain_config.flags is refused with MSDR_STATUS_ARGUMENT_ERROR */
 #define MSDR_CHAIN_NO_MFMA 8u        /* never run the FIR on the matrix cores (F32: split-fp16 MFMA kernel; Q15: byte-split i8 MFMA kernel) */
 #define MSDR_CHAIN_FOLD_ANY_PERIOD 64u /* F32, NCO: fold the mixer into the taps (matrix-core kernel) also when the oscillator table's only period is its
@@ -404,7 +409,7 @@ typedef struct {
 
 typedef struct msdr_chain msdr_chain;
 int msdr_chain_create(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_chain **out);
-/* d_if: int16 [channels][n_samples]; d_audio: int16 (Q15) or float (F32) [channels][n_samples].
+/* d_if: int16 [channels][n_samples]; d_audio: int16 (Q15, or F32 with MSDR_CHAIN_OUT_I16) or float (F32) [channels][n_samples].
  * State (FIR history, IIR state, NCO phase) is carried from call to call, so calling with
  * n_samples = 128 reproduces the reference's block cadence and one call with a long block is the
  * same stream.  Q15 arithmetic needs n_samples even when biquad nodes are present. */

@@ -1824,6 +1824,8 @@ struct msdr_chain {
     struct OscPending { void *d_tab; long long elapsed; };
     std::vector<OscPending> osc_pending;
     bool force_generic = false;          // the as-written kernel for the time being: no mode counts as numerator-folded
+    float *d_f32_scratch = nullptr;      // MSDR_CHAIN_OUT_I16 where the int16 conversion cannot happen in the main kernel: fp32 audio block batch
+    size_t f32_scratch_floats = 0;
     int arith, mixer, sqrt_kind;
     uint32_t channels, ntaps, ntaps_pad, hist_len, tapsets;
     uint32_t osc_len;
@@ -1942,6 +1944,7 @@ static void chain_free(msdr_chain *c)
     hipFree(c->d_anr_on);
     for (auto &e : c->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &o : c->osc_pending) hipFree(o.d_tab);
+    hipFree(c->d_f32_scratch);
     delete c;
 }
 
@@ -1984,7 +1987,7 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
     auto mode_ok = [](int m) { return m >= MSDR_MODE_SYNCAM && m <= MSDR_MODE_CW; };
     if (!mode_ok(cfg->default_mode)) return fail(MSDR_STATUS_ARGUMENT_ERROR, "bad default_mode");
     {
-        const uint32_t known = MSDR_CHAIN_NO_TAP_FOLDING | MSDR_CHAIN_NO_FFT | MSDR_CHAIN_NO_MFMA | MSDR_CHAIN_MFMA_WG | MSDR_CHAIN_SYNCAM_PLL | MSDR_CHAIN_FOLD_ANY_PERIOD;
+        const uint32_t known = MSDR_CHAIN_NO_TAP_FOLDING | MSDR_CHAIN_NO_FFT | MSDR_CHAIN_NO_MFMA | MSDR_CHAIN_MFMA_WG | MSDR_CHAIN_SYNCAM_PLL | MSDR_CHAIN_FOLD_ANY_PERIOD | MSDR_CHAIN_OUT_I16;
         if (cfg->flags & ~known) return fail(MSDR_STATUS_ARGUMENT_ERROR, "unknown bits 0x%x in msdr_chain_config.flags", cfg->flags & ~known);
     }
 
@@ -2674,7 +2677,7 @@ static int chain_post_build_steps(msdr_chain *c)
     for (uint32_t k = 0; k < c->osc_len; k++) { oq[k] = (float)c->h_osc[2 * k]; oi[k] = (float)c->h_osc[2 * k + 1]; }
     if (c->mixer == MSDR_MIXER_NCO) { a.osc_len = c->osc_len; a.osc_i = oi.data(); a.osc_q = oq.data(); }
     a.in_scale = c->in_scale; a.num_biquad_stages = 0; a.time_segments = 0;
-    a.flags = c->flags & ~(uint32_t)MSDR_CHAIN_SYNCAM_PLL;
+    a.flags = c->flags & ~(uint32_t)(MSDR_CHAIN_SYNCAM_PLL | MSDR_CHAIN_OUT_I16);      // (the auxiliary chain hands fp32 to the PLL / LMS steps)
     if (int rc = msdr_chain_create(c->ctx, &a, &c->aux)) return rc;
     c->aux->phase = c->phase;
     for (const auto &o : c->osc_pending) {          // the auxiliary chain takes the same raw history over: the same tables apply to it
@@ -2773,6 +2776,18 @@ static int chain_post_run(msdr_chain *c, const int16_t *d_if, float *d_audio, ui
     return launch_check("post_scatter_rows_kernel");
 }
 
+// fp32 audio -> int16 as arm_float_to_q15 (MSDR_CHAIN_OUT_I16 behind the kernels that do not convert in their own store phase)
+__global__ void f32_to_q15_kernel(const float *__restrict__ src, short *__restrict__ dst, long long total)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x * 4;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += stride) {
+        if (i + 4 <= total && ((reinterpret_cast<uintptr_t>(src + i) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dst + i) & 7) == 0))
+            *reinterpret_cast<u32x2 *>(dst + i) = mw_q15x4(*reinterpret_cast<const f32x4 *>(src + i));
+        else
+            for (long long e = i; e < total && e < i + 4; e++) dst[e] = mw_q15(src[e]);
+    }
+}
+
 static int chain_leave_generic(msdr_chain *c);
 extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_audio, uint64_t n_samples)
 {
@@ -2822,6 +2837,25 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     for (const auto &o : c->osc_pending) {
         if (p.n_osc_prev >= 4) break;
         p.osc_prev[p.n_osc_prev] = o.d_tab; p.osc_switch[p.n_osc_prev] = -o.elapsed; p.n_osc_prev++;
+    }
+    // ---- MSDR_CHAIN_OUT_I16: int16 audio.  The matrix-core kernels convert in their store phase when nothing runs behind them;
+    // otherwise the fp32 audio goes to a scratch block batch and is converted last.
+    void *fout = d_audio;                                        // where the fp32 passes of this call read and write the audio
+    bool i16_via_scratch = false;
+    if (f32 && (c->flags & MSDR_CHAIN_OUT_I16)) {
+        bool post_active = c->f32_pll || c->aux != nullptr;
+        for (int v : c->h_anr) if (v > 0) { post_active = true; break; }
+        if (use_mfw && !c->seq_bq && !post_active) p.out_i16 = 1;
+        else {
+            const size_t need = (size_t)c->channels * n_samples;
+            if (need > c->f32_scratch_floats) {
+                HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+                hipFree(c->d_f32_scratch); c->d_f32_scratch = nullptr; c->f32_scratch_floats = 0;
+                HIP_TRY(hipMalloc((void **)&c->d_f32_scratch, need * sizeof(float)));
+                c->f32_scratch_floats = need;
+            }
+            fout = c->d_f32_scratch; p.out = fout; i16_via_scratch = true;
+        }
     }
     if (use_qm)
         for (int ts : c->h_tapset) if (!c->qm_set_ok[ts]) { use_qm = false; break; }      // a tap >= 32640: the VALU kernel runs
@@ -3066,7 +3100,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     if (e0) { HIP_TRY(hipEventRecord(e1, c->ctx->stream)); c->events.emplace_back(e0, e1); }
 
     if (c->seq_bq)             // F32, ill-conditioned cascade: arm_biquad_cascade_df1_f32 in CMSIS order, in place on the audio
-        if (int rc = msdr_biquad_df1_f32_process(c->seq_bq, (const float *)d_audio, (float *)d_audio, (uint32_t)n_samples)) return rc;
+        if (int rc = msdr_biquad_df1_f32_process(c->seq_bq, (const float *)fout, (float *)fout, (uint32_t)n_samples)) return rc;
 
     if (pll_active)            // SYNCAM channels: I (in d_audio) and Q (scratch) -> PLL demodulator -> audio, before the biquad nodes
         if (int rc = msdr_syncam_q15(c->pll, c->d_mode, (const q15_t *)d_audio, c->d_pll_q, (q15_t *)d_audio, (uint32_t)n_samples)) return rc;
@@ -3103,7 +3137,12 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
 
     // rows f2 / f3 inside the fp32 chain: PLL / LMS channels are redone behind the main kernel (before the history moves on: a rebuilt
     // auxiliary chain takes over the history and table position this call started from)
-    if (f32) if (int rc = chain_post_run(c, d_if, (float *)d_audio, n_samples)) return rc;
+    if (f32) if (int rc = chain_post_run(c, d_if, (float *)fout, n_samples)) return rc;
+    if (i16_via_scratch) {
+        const long long total = (long long)c->channels * (long long)n_samples;
+        hipLaunchKernelGGL(f32_to_q15_kernel, dim3(grid_1d((total + 3) / 4)), dim3(256), 0, c->ctx->stream, (const float *)fout, (short *)d_audio, total);
+        if (int rc = launch_check("f32_to_q15_kernel")) return rc;
+    }
 
     hipLaunchKernelGGL((history_kernel<int16_t>), dim3(grid_1d((long long)c->channels * c->hist_len)), dim3(256), 0, c->ctx->stream,
                        d_if, (const int16_t *)c->d_hist[c->cur], c->d_hist[c->cur ^ 1], (long long)n_samples, (int)c->hist_len,

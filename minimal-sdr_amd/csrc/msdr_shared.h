@@ -100,6 +100,7 @@ struct ChainParams {
     const void *osc_prev[4];
     long long osc_switch[4];
     int n_osc_prev;
+    int out_i16;               // chain_mfw_kernel / chain_amtr_kernel, F32: `out` is int16 [channels][n], written as arm_float_to_q15 converts (MSDR_CHAIN_OUT_I16)
 };
 
 }  // namespace msdr

@@ -22,6 +22,7 @@ CHAIN_NO_TAP_FOLDING = 1
 CHAIN_NO_MFMA = 8
 CHAIN_SYNCAM_PLL = 32
 CHAIN_FOLD_ANY_PERIOD = 64
+CHAIN_OUT_I16 = 128
 FE_DCBLOCK, FE_AMP, FE_AGC, FE_ALL = 1, 2, 4, 7
 
 STATUS_ARGUMENT_ERROR, STATUS_LENGTH_ERROR, STATUS_NO_DEVICE = -1, -2, -100

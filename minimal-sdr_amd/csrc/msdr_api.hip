@@ -3309,6 +3309,17 @@ extern "C" int msdr_chain_set_mode(msdr_chain *c, uint32_t channel, int32_t mode
 // ---- live updates (include/msdr.h): the chain's tables are rebuilt by msdr_chain_create from the edited configuration, every piece of
 // STATE moves from the running chain into the rebuilt one, and the two structs trade places, so the caller's handle now names the new
 // tables over the old state.  The stream is drained first: the old tables are freed with the husk.
+// raw IF history carried into a rebuilt chain whose history length differs (a cascade that moves between the chain kernel and the
+// CMSIS-order pass changes the matrix-core window's halo): the newest min(hl_src, hl_dst) samples, older entries zero; both "oldest first"
+__global__ void hist_resize_kernel(const int16_t *__restrict__ src, int16_t *__restrict__ dst, int channels, int hl_src, int hl_dst)
+{
+    const long long total = (long long)channels * hl_dst;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i / hl_dst), k = (int)(i - (long long)ch * hl_dst), back = hl_dst - k;       // back = 1: the newest sample
+        dst[i] = (back <= hl_src) ? src[(long long)ch * hl_src + (hl_src - back)] : (int16_t)0;
+    }
+}
+
 static int chain_rebuild(msdr_chain *c, const ChainCfgStore &edited, void **steal_osc = nullptr)
 {
     HIP_TRY(hipStreamSynchronize(c->ctx->stream));
@@ -3319,12 +3330,19 @@ static int chain_rebuild(msdr_chain *c, const ChainCfgStore &edited, void **stea
     const int rc = msdr_chain_create(c->ctx, &cfg, &n);
     g_chain_floor_d = 0.0; g_chain_floor_sig = 0.0;
     if (rc) return rc;
-    if (n->hist_len != c->hist_len || n->channels != c->channels || n->osc_len != c->osc_len) {
+    if (n->channels != c->channels || n->osc_len != c->osc_len || n->ntaps != c->ntaps) {
         chain_free(n);
         return fail(MSDR_STATUS_SIZE_MISMATCH, "internal: a live update changed the chain's geometry");
     }
     // FIR history and table position
-    std::swap(n->d_hist[0], c->d_hist[0]); std::swap(n->d_hist[1], c->d_hist[1]); n->cur = c->cur; n->phase = c->phase;
+    if (n->hist_len == c->hist_len) { std::swap(n->d_hist[0], c->d_hist[0]); std::swap(n->d_hist[1], c->d_hist[1]); n->cur = c->cur; }
+    else {
+        hipLaunchKernelGGL(hist_resize_kernel, dim3(grid_1d((long long)n->channels * n->hist_len)), dim3(256), 0, c->ctx->stream,
+                           (const int16_t *)c->d_hist[c->cur], n->d_hist[n->cur], (int)n->channels, (int)c->hist_len, (int)n->hist_len);
+        if (int rc2 = launch_check("hist_resize_kernel")) { chain_free(n); return rc2; }
+        HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    }
+    n->phase = c->phase;
     // fp32 cascade state (the callers that change the cascade itself rewrite it afterwards)
     if (n->d_bq_state && c->d_bq_state) std::swap(n->d_bq_state, c->d_bq_state);
     if (n->seq_bq && c->seq_bq) std::swap(n->seq_bq, c->seq_bq);
@@ -3406,6 +3424,10 @@ static int chain_rebuild_keep_folded(msdr_chain *c, const ChainCfgStore &edited,
         c->force_generic = true;
     }
     if (!fix.empty() && c->d_bq_state) {
+        if (hist.size() != (size_t)c->channels * c->hist_len) {
+            hist.resize((size_t)c->channels * c->hist_len);
+            HIP_TRY(hipMemcpy(hist.data(), c->d_hist[c->cur], hist.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+        }
         for (uint32_t ch : fix) {
             float *r = st.data() + (size_t)ch * kBqStateFloats;
             const double *D = Dall.data() + (size_t)ch * 8;
@@ -3497,6 +3519,10 @@ extern "C" int msdr_chain_set_biquad_coeffs(msdr_chain *c, const float32_t *coef
     const int rrc = chain_rebuild(c, ed);
     if (rrc) { c->seq_bq = old_seq; return rrc; }
     if (old_seq) msdr_biquad_df1_f32_destroy(old_seq);
+    if (hist.size() != (size_t)c->channels * c->hist_len) {      // (the history length follows the cascade's place: read the carried-over copy)
+        hist.resize((size_t)c->channels * c->hist_len);
+        HIP_TRY(hipMemcpy(hist.data(), c->d_hist[c->cur], hist.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+    }
     if (c->seq_bq) {
         if (int rc = biquad_df1_write_cmsis(c->seq_bq, br, Y, D)) return rc;
     } else {

@@ -24,7 +24,8 @@ def test_two_rank_rehearsal_prints_one_complete_line():
     assert len(lines) == 1                                       # rank 0 prints, nobody else
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and len(d["rank_devices"]) == 2 and d["scaling"] == "weak"
-    assert set(d["also"]) == {"fir", "c2", "c4", "c5"}
+    assert set(d["also"]) == {"fir", "c2", "c4", "c5", "q15_c3", "c3_i16"}
+    assert d["library_rev"]
     for name, rec in [("c3", d)] + list(d["also"].items()):
         assert rec["roofline"]["frac"] > 0, name
         if name != "fir":                                        # (the FIR stage's parity needs the CPU leg, off here)

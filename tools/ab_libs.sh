@@ -14,7 +14,7 @@ import json, sys
 try:
     d = json.load(open('gpurun_out/ab_x.json'))
     r = d['roofline']; p = d.get('parity', {})
-    print('%-4s %-40s kernel_ms %.4f frac %.4f sclk %s W %s parity %s' % (sys.argv[1], sys.argv[2].split('/')[-1], r['kernel_ms'], r['frac'], r.get('sclk_mhz'), r.get('power_w'),
+    print('%-4s %-40s step_ms %.4f kernel_ms %.4f frac %.4f sclk %s W %s parity %s' % (sys.argv[1], sys.argv[2].split('/')[-1], d['ms_per_step'], r['kernel_ms'], r['frac'], r.get('sclk_mhz'), r.get('power_w'),
           p.get('rel_rms_worst', p.get('mismatching_samples'))))
 except Exception as e:
     print(sys.argv[1], sys.argv[2], 'FAILED', e)

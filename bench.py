@@ -54,6 +54,8 @@ def power_probe(step, torch, dev, device_index, world):
     Single-GPU runs only (rank 0 would otherwise hold the other ranks at the next barrier)."""
     if world != 1:
         return {"sclk_mhz": None, "power_w": None, "power_note": "sampled on single-GPU runs only"}
+    if os.environ.get("MSDR_BENCH_NO_POWER", "0") == "1":       # profiler runs (tools/profile.sh): no helper thread, no child process
+        return {"sclk_mhz": None, "power_w": None, "power_note": "not sampled (MSDR_BENCH_NO_POWER=1)"}
     import re
     import subprocess
     import threading
@@ -670,7 +672,7 @@ def attach_traffic(out, tag, args):
     THIS run launched (names compared) and the run is the named configuration: any shape override, experiment switch or MSDR_*
     kernel-selection variable leaves `traffic` null."""
     if (args.samples or args.channels or args.taps or args.stages >= 0 or args.no_mfma or args.no_fold or getattr(args, "out_i16", False)
-            or args.time_segments or args.osc_period != 4 or any(k.startswith("MSDR_") and k not in ("MSDR_LIB", "MSDR_BENCH_REHEARSAL") for k in os.environ)):
+            or args.time_segments or args.osc_period != 4 or any(k.startswith("MSDR_") and k not in ("MSDR_LIB", "MSDR_BENCH_REHEARSAL", "MSDR_BENCH_NO_POWER") for k in os.environ)):
         return
     ran = str(out["config"].get("kernel", "")).split("<")[0].split(" ")[0]
     for rnd in ("r04", "r03", "r02", "r01"):

@@ -4,6 +4,7 @@ set -u
 W=$1
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 export TMPDIR=/tmp
+export MSDR_BENCH_NO_POWER=1      # no rocm-smi child process under the profiler
 OUT=gpurun_out/pmc_coexec_$W
 rm -rf "$OUT"; mkdir -p "$OUT"
 i=0

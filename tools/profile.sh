@@ -7,6 +7,7 @@ set -u
 TAG=$1; shift
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 export TMPDIR=/tmp
+export MSDR_BENCH_NO_POWER=1      # no rocm-smi child process under the profiler
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 ARGS="$* --no-cpu"

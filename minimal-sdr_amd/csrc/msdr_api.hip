@@ -3185,6 +3185,11 @@ extern "C" int msdr_chain_reset(msdr_chain *c)
         for (uint32_t ch = 0; ch < c->channels; ch++) { h[(size_t)ch * kAnrStateFloats] = 120.0f; h[(size_t)ch * kAnrStateFloats + 1] = 0.001f; }
         HIP_TRY(hipMemcpy(c->d_post_anr_state, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    if (!c->osc_pending.empty() || c->force_generic) {          // no sample of an earlier oscillator table is left in a cleared history
+        HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+        for (auto &o : c->osc_pending) hipFree(o.d_tab);
+        c->osc_pending.clear(); c->force_generic = false;
+    }
     c->phase = 0; c->gen++;
     return 0;
 }
@@ -3340,7 +3345,7 @@ static int chain_rebuild(msdr_chain *c, const ChainCfgStore &edited, void **stea
         hipLaunchKernelGGL(hist_resize_kernel, dim3(grid_1d((long long)n->channels * n->hist_len)), dim3(256), 0, c->ctx->stream,
                            (const int16_t *)c->d_hist[c->cur], n->d_hist[n->cur], (int)n->channels, (int)c->hist_len, (int)n->hist_len);
         if (int rc2 = launch_check("hist_resize_kernel")) { chain_free(n); return rc2; }
-        HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+        if (hipStreamSynchronize(c->ctx->stream) != hipSuccess) { chain_free(n); return fail(MSDR_STATUS_HIP_ERROR, "hist_resize_kernel failed"); }
     }
     n->phase = c->phase;
     // fp32 cascade state (the callers that change the cascade itself rewrite it afterwards)

@@ -374,13 +374,15 @@ typedef struct {
     const float32_t *biquad_coeffs;  /* F32: host, 5*num_biquad_stages.  ACCURACY CONTRACT of the fp32 chain (tests/test_gpu_f32_contract.py):
                                       *   every output row is within 1e-5 relative RMS of arm_fir_f32 + arm_biquad_cascade_df1_f32 evaluated in CMSIS order in
                                       *   fp32 -- or, where that sequential fp32 evaluation is itself further than that from the exact (float64) result, within
-                                      *   TWICE its distance from the exact result (+ 1e-6).  The second clause matters for cascades whose sections ring
+                                      *   TWICE its distance from the exact result (+ fp32_noise + 1e-6, fp32_noise as below).  The second clause matters for cascades whose sections ring
                                       *   (narrow notches, resonant low / high-passes, three or more sections): their fp32 rounding noise, in any order of
                                       *   evaluation, is msdr_biquad_df1_f32_cascade_info()'s *fp32_noise (4e-7 for the reference's LP + notch; 1e-5 and more for
                                       *   random Q 8 sections below 1 kHz), and the block-parallel solver adds up to *kappa times the per-sample rounding; the
                                       *   library switches to the CMSIS order itself (one lane per channel behind the main kernel, *cmsis_order = 1) when
-                                      *   kappa > 30 (20 from three sections on), kappa x fp32_noise > 2e-5 or fp32_noise > 2e-6, and for three or four sections
-                                      *   behind the general kernel.  With the reference's filters and all BASELINE configurations: 5-6e-7. */
+                                      *   kappa > 30 (20 from three sections on), kappa x fp32_noise > 2e-5 or fp32_noise > 2e-6, when the ORDER "numerators first"
+                                      *   alone costs more than 1.5 x fp32_noise + 2e-7 on the host's test signal, and for three or four sections behind the
+                                      *   general kernel.  Where the cascade removes most of its input (stacked high-passes), 1e-5 and 1e-6 are referred to the
+                                      *   level of the cascade's input.  With the reference's filters and all BASELINE configurations: 5-6e-7. */
     uint32_t num_biquad_nodes;       /* Q15: 0..2 AudioFilterBiquad nodes in series (biquad1_dac, biquad2_dac) */
     uint32_t node_stages[2];         /* Q15: stages used in each node (1..4) */
     const int32_t *node_coefs[2];    /* Q15: host, 5*node_stages[k] ints as given to setCoefficients */

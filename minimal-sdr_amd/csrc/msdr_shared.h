@@ -48,6 +48,14 @@ struct BiquadCascadeTables {
 // per-channel cascade state in HBM: 16 floats = d[n-1..n-8] (numerator history) | (w1, w2) per section
 constexpr int kBqStateFloats = 16;
 
+// Oscillator tables that were in force before a live change, oldest first (device memory, behind ONE pointer of ChainParams: the
+// matrix-core kernels are at their register budget, every kernel argument costs them scalar registers).  A carried history sample at
+// time t < sw[k] (t relative to the call, so sw <= 0) was mixed with table k when it arrived (freq_conv.cpp:70-103 mixes each block with
+// the tables as they are at that update()), and chain_kernel<Arith> mixes it with that table again.
+struct OscHistory { const void *tab[4]; long long sw[4]; int n; };
+
+constexpr int kChainOutI16 = 0x40000000;
+
 struct ChainParams {
     const int16_t *x;          // [channels][n] IF samples
     void *out;                 // [channels][n] float (F32) or int16 (Q15)
@@ -91,16 +99,14 @@ struct ChainParams {
     const int *mf_units;       // [workgroups][mf_nw] pairs (channel, segment); channel < 0 = idle wave
     int mf_nw;                 // waves per workgroup (1..16)
     unsigned long long *dbg_buf;   // diagnostic build (-DMSDR_STAMPS): per-phase cycle sums, 8 per unit
-    int dbg;                   // diagnostic bits: read from MSDR_DBG by the -DMSDR_STAMPS build only; the product build never looks at it
+    int dbg;                   // diagnostic bits: read from MSDR_DBG by the -DMSDR_STAMPS build only; the product build looks at ONE bit of it:
+                               // kChainOutI16 -- chain_mfw_kernel / chain_amtr_kernel, F32: `out` is int16 [channels][n], written as arm_float_to_q15
+                               // converts (MSDR_CHAIN_OUT_I16).  (A bit of an existing field: these kernels are at their register budget and
+                               // every kernel argument costs them scalar registers -- a field of its own made the headline flavour spill.)
     const float *mw_iir;       // wave-stream kernel, folded IIR: MwIirConsts block (scan matrices, response fragments), or null
     float *bq_state_out;       // [channels][kBqStateFloats] cascade state after this call (ping-pong partner of bq_state)
-    // chain_kernel<Arith> only: oscillator tables that were in force before a live change (msdr_chain_set_osc), oldest first -- a carried
-    // history sample at time t < osc_switch[k] (t relative to this call, so osc_switch <= 0) was mixed with table k when it arrived
-    // (freq_conv.cpp:70-103 mixes each block with the tables as they are at that update()), and is mixed with it again here
-    const void *osc_prev[4];
-    long long osc_switch[4];
-    int n_osc_prev;
-    int out_i16;               // chain_mfw_kernel / chain_amtr_kernel, F32: `out` is int16 [channels][n], written as arm_float_to_q15 converts (MSDR_CHAIN_OUT_I16)
+    // chain_kernel<Arith> only: oscillator tables that were in force before a live change (msdr_chain_set_osc), or null -- see OscHistory
+    const struct OscHistory *osc_hist;
 };
 
 }  // namespace msdr

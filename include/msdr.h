@@ -379,8 +379,8 @@ typedef struct {
                                       *   evaluation, is msdr_biquad_df1_f32_cascade_info()'s *fp32_noise (4e-7 for the reference's LP + notch; 1e-5 and more for
                                       *   random Q 8 sections below 1 kHz), and the block-parallel solver adds up to *kappa times the per-sample rounding; the
                                       *   library switches to the CMSIS order itself (one lane per channel behind the main kernel, *cmsis_order = 1) when
-                                      *   kappa > 30 (20 from three sections on), kappa x fp32_noise > 2e-5 or fp32_noise > 2e-6, when the ORDER "numerators first"
-                                      *   alone costs more than 1.5 x fp32_noise + 2e-7 on the host's test signal, and for three or four sections behind the
+                                      *   kappa > 30 (20 from three sections on), kappa x fp32_noise > 2e-5 or fp32_noise > 2e-6, when a host-side emulation of
+                                      *   the block-parallel evaluation is more than 1.5 x fp32_noise + 2e-7 from float64 on the host's test signal, and for three or four sections behind the
                                       *   general kernel.  Where the cascade removes most of its input (stacked high-passes), 1e-5 and 1e-6 are referred to the
                                       *   level of the cascade's input.  With the reference's filters and all BASELINE configurations: 5-6e-7. */
     uint32_t num_biquad_nodes;       /* Q15: 0..2 AudioFilterBiquad nodes in series (biquad1_dac, biquad2_dac) */

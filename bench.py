@@ -113,6 +113,13 @@ def lowpass(n_taps, fc=2800.0):
     return (h / h.sum()).astype(np.float32)
 
 
+def lowpass_designer(msdr, n_taps, fc=2800.0):
+    """The low-pass as the REFERENCE designs it: calc_FIR_coeffs(FIR_AM_coeffs, n, filter_bandwidth, 70 dB, 0, 0, 24000) (calc_demod_filter,
+    Minimal-SDR.ino:221-223; designer :782-872, restated bit-exactly by the library's msdr_calc_FIR_coeffs), q15 taps converted as
+    arm_q15_to_float does.  Linear phase about an integer index (c[k] = c[n - k]): what chain_amsy_kernel's folded window needs."""
+    return (msdr.calc_fir_coeffs(n_taps, fc, 70.0, 0, 0.0, FS)[:n_taps].astype(np.float32) / 32768.0).astype(np.float32)
+
+
 def reference_biquads(msdr):
     """biquad1_dac: LP 0.9*6 kHz Q=0.54 (.ino:391-393); biquad2_dac: notch fs/8 Q=15 (.ino:356); CMSIS sign."""
     corr = msdr.AUDIO_SAMPLE_RATE_EXACT / FS
@@ -123,7 +130,7 @@ def reference_biquads(msdr):
     return np.array(out, np.float32)
 
 
-def workload(name, msdr, rank, osc_period=4):
+def workload(name, msdr, rank, osc_period=4, lp_design="numpy"):
     # freq_conv-style oscillator: the reference's tables are q15 (Osc_I/Q_buffer_i, freq_conv.h:33-34), one
     # AUDIO_BLOCK long, here at fs/4; converted to float as arm_q15_to_float does (/32768)
     osc_n = np.arange(128)
@@ -136,7 +143,7 @@ def workload(name, msdr, rank, osc_period=4):
                     channels=1, n=1 << 30, taps=100, ci=[hi], cq=[hq], mixer=msdr.MIXER_NCO, osc=(osc_i, osc_q),
                     modes=None, tapsets=None, mode=msdr.MODE_LSB, bq=bq, seed=2 + 1000 * rank)
     if name == "c3":
-        lp = lowpass(256)
+        lp = lowpass_designer(msdr, 256) if lp_design == "designer" else lowpass(256)
         return dict(name="c3: 4096 AM channels x 2^18, Fs/4 mix + 256-tap low-pass pair + envelope + 2-stage biquad",
                     channels=4096, n=1 << 18, taps=256, ci=[lp], cq=[lp], mixer=msdr.MIXER_FS4, osc=None,
                     modes=None, tapsets=None, mode=msdr.MODE_AM, bq=bq, seed=3 + 1000 * rank)
@@ -147,7 +154,7 @@ def workload(name, msdr, rank, osc_period=4):
                     modes=None, tapsets=None, mode=msdr.MODE_LSB, bq=bq, seed=4 + 1000 * rank)
     if name == "c5":
         ch = 256
-        lp = lowpass(512)
+        lp = lowpass_designer(msdr, 512) if lp_design == "designer" else lowpass(512)
         hi, hq = hilbert_pair(512)
         modes = np.array([msdr.MODE_AM if ((c + ch * rank) * 2654435761 >> 7) & 1 else msdr.MODE_LSB for c in range(ch)], np.int32)
         tapsets = np.array([0 if m == msdr.MODE_AM else 1 for m in modes], np.int32)
@@ -766,7 +773,7 @@ def chain_parity(wl, captured, q15, orc, orclib, out_i16=False):
 
 def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do_gather):
     """One record of the fused chain (c2 .. c5)."""
-    wl = workload(name, msdr, rank, args.osc_period)
+    wl = workload(name, msdr, rank, args.osc_period, args.lowpass)
     if args.samples:
         wl["n"] = args.samples
     if args.channels:
@@ -1050,6 +1057,9 @@ def main():
     ap.add_argument("--osc-period", type=int, default=4, help="experiment: NCO period in samples (4 = fs/4, the named config)")
     ap.add_argument("--stages", type=int, default=-1, help="experiment: override the number of biquad stages (0..2)")
     ap.add_argument("--taps", type=int, default=0, help="experiment: override the tap count (same designer)")
+    ap.add_argument("--lowpass", default="numpy", choices=["designer", "numpy"],
+                    help="the AM low-pass of c3 / c5: designer = the reference's calc_FIR_coeffs (linear phase about an integer index); numpy = a windowed sinc "
+                         "centred on a half sample (rounds 1-3)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -16,7 +16,6 @@
 #include "msdr_fir_f32tr.hiph"
 #include "msdr_fir_f32tq.hiph"
 #include "msdr_chain_amtr.hiph"
-#include "msdr_chain_amsy.hiph"
 #include "msdr_design.h"
 #include "msdr_cascade_state.h"
 
@@ -1943,7 +1942,6 @@ struct msdr_chain {
     uint32_t flags;
     int mfw_nw, mfw_waves_per_cu;
     char *d_at_tab; int at_ns, at_stride, at_nw;          // envelope channels with the taps in registers (msdr_chain_amtr.hiph), or null
-    bool at_sym;                                         // ... on the linear-phase kernel (msdr_chain_amsy.hiph): at_ns = its step count
     bool mf_fr;                                           // full-rate layout (msdr_chain_mfw.hiph): any 128-periodic oscillator table, mixer products staged as two streams
     float *d_bq_state_alt;
     float *d_mw_iir;                  // folded-IIR constants (MwIirConsts) or null
@@ -2110,7 +2108,7 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
     c->flags = cfg->flags; c->mfw_nw = 0; c->mfw_waves_per_cu = 0; c->d_bq_state_alt = nullptr; c->d_mw_iir = nullptr; c->d_units = nullptr; c->units_cap = 0;
     c->mode_gen = 1; c->units_mode_gen = 0; c->units_nseg = 0; c->units_wgs = 0; c->units_wgs_ssb = 0; c->mfw_ssb_fold = false; c->mfw_am_fold = false; c->units_tiles = -1;
     c->part_nseg[0] = c->part_nseg[1] = 1; c->part_seg_len[0] = c->part_seg_len[1] = 0;
-    c->d_at_tab = nullptr; c->at_ns = 0; c->at_stride = 0; c->at_nw = 0; c->at_sym = false;
+    c->d_at_tab = nullptr; c->at_ns = 0; c->at_stride = 0; c->at_nw = 0;
     c->d_qm_tab = nullptr; c->d_qm_order = nullptr; c->qm_stride = 0; c->qm_halo = 0; c->qm_bsteps = 0; c->qm_order_gen = 0; c->qm_fr = false;
     c->pll = nullptr; c->d_pll_q = nullptr; c->pll_q_cap = 0;
     c->anr = nullptr; c->d_anr_on = nullptr; c->anr_all = 0;
@@ -2626,84 +2624,9 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
         }
     }
     if (c->mf_fr && !c->mf_ok) { c->mf_fr = false; c->mf_P = 0; }
-    // ---- envelope channels with LINEAR-PHASE taps (msdr_chain_amsy.hiph): the exact Fs/4 mixer, both FIRs of every tap set with the same
-    // taps, every tap set symmetric about an integer delay (what calc_FIR_coeffs designs, Minimal-SDR.ino:782-872): the folded-window products.
-    // MSDR_AMSY=0 keeps the other kernels (tests compare the two).
-    if (getenv("MSDR_AMSY_DEBUG")) fprintf(stderr, "amsy: rc %d f32 %d mf_ok %d nw %d fr %d mixer %d flags %x ntaps %u st %u\n", rc, (int)f32, (int)c->mf_ok, c->mfw_nw, (int)c->mf_fr, (int)cfg->mixer, (unsigned)cfg->flags, c->ntaps, c->nstages);
-    if (!rc && f32 && c->mf_ok && c->mfw_nw > 0 && !c->mf_fr && cfg->mixer == MSDR_MIXER_FS4 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) &&
-        c->ntaps >= 2 && c->nstages <= 2 && !(getenv("MSDR_AMSY") && atoi(getenv("MSDR_AMSY")) == 0)) {
-        const int N = (int)c->ntaps;
-        bool ok_sy = true;
-        std::vector<int> d0s(c->tapsets, 0);
-        int ns = 2;
-        for (uint32_t s2 = 0; s2 < c->tapsets && ok_sy; s2++) {
-            ok_sy = memcmp(cfg->coeffs_i[s2], cfg->coeffs_q[s2], (size_t)N * sizeof(float)) == 0;
-            if (!ok_sy) break;
-            const float *h = (const float *)cfg->coeffs_i[s2];
-            auto hd = [&](int d) -> double { return (d >= 0 && d < N) ? (double)h[N - 1 - d] : 0.0; };      // taps by delay
-            int lo = -1, hi2 = -1;
-            for (int d = 0; d < N; d++) if (hd(d) != 0.0) { if (lo < 0) lo = d; hi2 = d; }
-            if (lo < 0 || ((lo + hi2) & 1)) { ok_sy = false; break; }
-            const int D0 = (lo + hi2) / 2;
-            for (int d = 0; d < N && ok_sy; d++) ok_sy = hd(d) == hd(2 * D0 - d);
-            d0s[s2] = D0;
-            ns = std::max(ns, D0 <= 96 ? 2 : D0 <= 160 ? 3 : 5);
-            if (D0 > sy_hh(kSyMaxSteps)) ok_sy = false;
-        }
-        for (uint32_t s2 = 0; s2 < c->tapsets && ok_sy; s2++) ok_sy = d0s[s2] <= sy_hh(ns) && d0s[s2] + 96 >= 32 * ns && d0s[s2] >= 1;
-        if (getenv("MSDR_AMSY_DEBUG")) fprintf(stderr, "amsy: ok %d ns %d d0 %d N %d tapsets %u\n", (int)ok_sy, ns, d0s[0], N, c->tapsets);
-        int nw = 8;
-        while (ok_sy && nw > 1 && sy_lds_bytes(ns, nw) > 160 * 1024) nw--;
-        if (ok_sy && sy_lds_bytes(ns, nw) <= 160 * 1024) {
-            const size_t stride = sy_table_bytes(ns);
-            std::vector<char> blob(stride * c->tapsets, 0);
-            for (uint32_t s2 = 0; s2 < c->tapsets; s2++) {
-                const float *h = (const float *)cfg->coeffs_i[s2];
-                const int D0 = d0s[s2];
-                // g[d] = h_by_delay[d] j^-d as in the taps-in-registers kernel; aR[j] = gR[2 j] (D0 + 1 taps), aI[j] = gI[2 j + 1] (D0 taps)
-                auto gR = [&](int d) -> double { return (d >= 0 && d < N && !(d & 1)) ? (double)h[N - 1 - d] * ((d & 2) ? -1.0 : 1.0) : 0.0; };
-                auto gI = [&](int d) -> double { return (d >= 0 && d < N && (d & 1)) ? (double)h[N - 1 - d] * ((d & 2) ? 1.0 : -1.0) : 0.0; };
-                std::vector<double> M((size_t)4 * 32 * ns * 16, 0.0);             // [matrix][k][row]
-                double maxabs = 0.0;
-                for (int typ = 0; typ < 2; typ++) {
-                    const int J = typ == 0 ? D0 + 1 : D0, K = J + 31;
-                    const bool eps_pos = ((D0 & 1) == 0) == (typ == 0);           // eps_R = (-1)^D0, eps_I = -eps_R
-                    auto a = [&](int j) -> double { return (j < 0 || j >= J) ? 0.0 : (typ == 0 ? gR(2 * j) : gI(2 * j + 1)); };
-                    auto T = [&](int pp, int k) -> double { return a(pp + J - 1 - k); };
-                    for (int r = 0; r < 16; r++)
-                        for (int k = 0; k < (K + 1) / 2; k++) {
-                            double U = T(r, k) + T(31 - r, k), V = T(r, k) - T(31 - r, k);
-                            if ((K & 1) && k == K / 2) { U *= 0.5; V *= 0.5; }    // the middle sample meets itself: the kernel adds it twice
-                            M[((size_t)(2 * typ) * 32 * ns + k) * 16 + r] = eps_pos ? U : V;          // meets up + down
-                            M[((size_t)(2 * typ + 1) * 32 * ns + k) * 16 + r] = eps_pos ? V : U;      // meets up - down
-                            maxabs = std::max(maxabs, std::max(std::fabs(U), std::fabs(V)));
-                        }
-                }
-                int ex = 0;
-                if (maxabs > 0) { (void)std::frexp(maxabs, &ex); ex = 14 - ex; }             // maxabs 2^ex in [2^13, 2^14)
-                AmSyHeader hd2;
-                memset(&hd2, 0, sizeof hd2);
-                hd2.ns = ns; hd2.d0 = D0; hd2.post = (float)(16.0 * (double)c->in_scale / std::ldexp(1.0, ex));
-                memcpy(blob.data() + s2 * stride, &hd2, sizeof hd2);
-                _Float16 *tf = reinterpret_cast<_Float16 *>(blob.data() + s2 * stride + kSyHdrBytes);
-                for (int m = 0; m < 4; m++)
-                    for (int st = 0; st < ns; st++)
-                        for (int l = 0; l < 64; l++)
-                            for (int jj = 0; jj < 8; jj++) {
-                                const int k = sy_kslot(st, l >> 4, jj);
-                                const double v = M[((size_t)m * 32 * ns + k) * 16 + (l & 15)] * std::ldexp(1.0, ex);
-                                const _Float16 vh = (_Float16)v;
-                                const size_t o = ((size_t)(m * ns + st) * 2) * 512 + l * 8 + jj;
-                                tf[o] = vh; tf[o + 512] = (_Float16)(v - (double)vh);
-                            }
-            }
-            rc = upload(ctx, blob, &c->d_at_tab);
-            c->at_ns = ns; c->at_stride = (int)stride; c->at_nw = nw; c->at_sym = true;
-        }
-    }
     // ---- envelope channels with the taps in registers (msdr_chain_amtr.hiph): the exact Fs/4 mixer, both FIRs of every tap set with the
     // same taps (the reference's AM case, Minimal-SDR.ino:917-924), up to 257 taps; rides on the wave-stream kernel's unit table ----
-    if (!rc && !c->at_sym && f32 && c->mf_ok && c->mfw_nw > 0 && !c->mf_fr && cfg->mixer == MSDR_MIXER_FS4 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) &&
+    if (!rc && f32 && c->mf_ok && c->mfw_nw > 0 && !c->mf_fr && cfg->mixer == MSDR_MIXER_FS4 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) &&
         at_steps((int)c->ntaps) <= kAtMaxSteps && c->ntaps >= 2 &&
         // where it wins (256 taps with 0 / 1 biquad sections: 7 - 11 % faster than the wave-stream kernel in round 2, profiles/r02/am_matrix.txt;
         // 2 - 4 % after round 3's work on the other kernel, profiles/r03/c3_trims.txt; shorter filters or 2+ sections: equal or slower, the other
@@ -3156,20 +3079,6 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
                 const long long entries = (long long)g * c->mfw_nw;
                 a.mf_tab = c->d_at_tab; a.mf_stride = c->at_stride; a.mf_nw = c->at_nw; a.fold_rot = (int)entries;
                 const unsigned ag = (unsigned)((entries + c->at_nw - 1) / c->at_nw);
-                if (c->at_sym) {
-                    const size_t slds = sy_lds_bytes(c->at_ns, c->at_nw);
-#define MSDR_SY_LAUNCH(NS_, SS_) hipLaunchKernelGGL((chain_amsy_kernel<NS_, SS_>), dim3(ag), dim3(c->at_nw * 64), slds, c->ctx->stream, a)
-#define MSDR_SY_STAGES(NS_) switch (c->nstages) { case 0: MSDR_SY_LAUNCH(NS_, 0); break; case 1: MSDR_SY_LAUNCH(NS_, 1); break; default: MSDR_SY_LAUNCH(NS_, 2); break; }
-                    switch (c->at_ns) {
-                    case 2: MSDR_SY_STAGES(2) break;
-                    case 3: MSDR_SY_STAGES(3) break;
-                    default: MSDR_SY_STAGES(5) break;
-                    }
-#undef MSDR_SY_STAGES
-#undef MSDR_SY_LAUNCH
-                    if (int rc2 = launch_check("chain_amsy_kernel")) return rc2;
-                    continue;
-                }
                 const size_t alds = at_lds_bytes(c->at_ns, c->at_nw);
 #define MSDR_AT_LAUNCH(NS_, SS_) hipLaunchKernelGGL((chain_amtr_kernel<NS_, SS_>), dim3(ag), dim3(c->at_nw * 64), alds, c->ctx->stream, a)
 #define MSDR_AT_STAGES(NS_) switch (c->nstages) { case 0: MSDR_AT_LAUNCH(NS_, 0); break; case 1: MSDR_AT_LAUNCH(NS_, 1); break; case 2: MSDR_AT_LAUNCH(NS_, 2); break; \
@@ -3205,9 +3114,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         static const char *const names_fr[5] = {"chain_mfw_kernel<0> full-rate NCO streams", "chain_mfw_kernel<1> full-rate NCO streams", "chain_mfw_kernel<2> full-rate NCO streams",
                                                 "chain_mfw_kernel<3> full-rate NCO streams", "chain_mfw_kernel<4> full-rate NCO streams"};
         kname = c->mf_fr ? names_fr[c->nstages] : names[c->nstages];
-        if (c->d_at_tab && c->units_wgs > c->units_wgs_ssb)
-            kname = c->at_sym ? (c->units_wgs_ssb ? "chain_mfw_kernel + chain_amsy_kernel" : "chain_amsy_kernel")
-                              : (c->units_wgs_ssb ? "chain_mfw_kernel + chain_amtr_kernel" : "chain_amtr_kernel");
+        if (c->d_at_tab && c->units_wgs > c->units_wgs_ssb) kname = c->units_wgs_ssb ? "chain_mfw_kernel + chain_amtr_kernel" : "chain_amtr_kernel";
         std::swap(c->d_bq_state, c->d_bq_state_alt);          // the kernel read bq_state and wrote bq_state_out
 #ifdef MSDR_STAMPS
         if (getenv("MSDR_STAMP_PRINT")) {

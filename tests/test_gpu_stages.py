@@ -548,3 +548,38 @@ def test_fir_f32_every_output_of_a_batch_larger_than_the_resident_waves(ctx):
         t = truth[c][:(n // 1024) * 1024].reshape(-1, 1024)
         per_tile = np.sqrt((d ** 2).sum(axis=1) / (t ** 2).sum(axis=1))
         assert per_tile.max() < 2e-6, (c, int(per_tile.argmax()), float(per_tile.max()))
+
+
+@pytest.mark.parametrize("shift", [1, 2, 3])
+def test_fir_f32_tile_queue_runs_of_tiles(ctx, orc, shift, monkeypatch):
+    """Round 4: a draw hands a wave a RUN of 2^shift consecutive tiles, and the second .. last tile of a run inside one row take their
+    1 KB halo from the registers that hold the tile before (256-tap class: the halo is exactly the window's first load).  By itself the
+    library uses runs only where every wave still gets >= 16 of them (the bench shape); MSDR_TQ_RUN_SHIFT forces them here: rows of 1,
+    2^shift - 1, 2^shift + 1 and many tiles, rows that end inside a run, runs that straddle rows, two calls (history), EVERY output of
+    every row against a float64 convolution, NaN-filled output; 100 taps as well (runs without the register halo)."""
+    from scipy.signal import fftconvolve
+    monkeypatch.setenv("MSDR_TQ_RUN_SHIFT", str(shift))
+    for ntaps, ch, sizes in ((256, 96, (40 * 1024 + 333, 7 * 1024)), (256, 7, (1024 * ((1 << shift) + 1), 1024 * ((1 << shift) - 1) + 5, 1024)),
+                             (241, 300, (9 * 1024,)), (100, 64, (12 * 1024 + 17, 2048))):
+        rng = np.random.default_rng(ntaps + ch + shift)
+        h = (rng.standard_normal(ntaps) * np.hanning(ntaps + 2)[1:-1]).astype(np.float32)
+        n = sum(sizes)
+        x = rng.uniform(-8000, 8000, (ch, n)).astype(np.float32)
+        x[:, ::1024] += 5.0e4                                      # a marker on every tile's first sample
+        fir = msdr.FirF32(ctx, h, ch)
+        got = np.empty_like(x)
+        o = 0
+        for m in sizes:
+            dx, dy = ctx.to_device(np.ascontiguousarray(x[:, o:o + m])), ctx.to_device(np.full((ch, m), np.nan, np.float32))
+            fir.process(dx, dy, m)
+            got[:, o:o + m] = dy.download()
+            o += m
+        assert not np.isnan(got).any(), (ntaps, ch)
+        truth = fftconvolve(x.astype(np.float64), h.astype(np.float64)[::-1][None, :], axes=1)[:, :n]
+        err = np.sqrt(((got - truth) ** 2).sum(axis=1) / (truth ** 2).sum(axis=1))
+        assert err.max() < 1e-6, (ntaps, ch, int(err.argmax()), float(err.max()))
+        full = (n // 1024) * 1024
+        d = (got[:, :full] - truth[:, :full]).reshape(ch, -1, 1024)
+        t = truth[:, :full].reshape(ch, -1, 1024)
+        per_tile = np.sqrt((d ** 2).sum(axis=2) / (t ** 2).sum(axis=2))
+        assert per_tile.max() < 3e-6, (ntaps, ch, np.unravel_index(int(per_tile.argmax()), per_tile.shape), float(per_tile.max()))

@@ -92,6 +92,7 @@ int main(int argc, char **argv)
     q.x = x; q.y = y; q.hist = hist; q.tab = tab; q.n = n; q.channels = channels; q.hist_len = hist_len;
     q.tpr = (unsigned)(n / kTrTile); q.tpr_shift = 8; q.total = q.tpr * channels; q.fronts = fronts; q.per_front = (q.total + fronts - 1) / fronts;
     q.all_aligned = 1;
+    q.run_shift = getenv("MSDR_TQ_RUN_SHIFT") ? atoi(getenv("MSDR_TQ_RUN_SHIFT")) : 2;
     const unsigned grid = 512;
     const size_t lds = 4 * tr_wave_bytes(trs);
     CHECK(hipDeviceSynchronize());

@@ -7,11 +7,14 @@
 #   arm_fir_init_q15   src/CMSIS_5/arm_fir_init_q15.c:78-138   (A3, Cortex-M4 branch)
 #   arm_copy_q15       src/CMSIS_5/arm_copy_q15.c:48-98
 #   arm_sqrt_q31       src/CMSIS_5/arm_sqrt_q31.c:50-138       (A5, Teensy-3.2 AM variant)
+#   arm_sqrt_f32       src/CMSIS_5/arm_math.h:5733-5758        (A5, Teensy-3.6 AM variant: a static inline of the header, through a caller)
 #   calc_FIR_coeffs / m_sinc / Izero   Minimal-SDR.ino:782-899 (A9)
 #   row f4 (spectrum, UI.cpp:520-592 -> arm_rfft_q15): arm_cfft_radix4_q15.c (arm_cfft_radix4_q15,
 #   arm_radix4_butterfly_q15), arm_cfft_radix4_init_q15.c, arm_bitreversal.c (arm_bitreversal_q15),
 #   arm_split_rfft_q15 (arm_rfft_q15.c:128-283), arm_rfft_init_q15.c, arm_const_structs.c,
 #   arm_common_tables.c (twiddle / bit-reversal / realCoef tables as data)
+#   rows A7 / f1, the arithmetic primitives only: signed_multiply_32x16b/t, signed_saturate_rshift, pack_16b_16b / 16t_16t / 16t_16b
+#   (src/Audio/utility/dspinst.h:34-51, :70-92, :151-184, the header's own plain-C `KINETISL` bodies)
 #
 # How the two non-trivial cases are handled WITHOUT hand-written stand-ins:
 #  * arm_fir_fast_q15.c needs __SMLAD/__SMLADX/__PKHBT.  The reference header arm_math.h
@@ -98,7 +101,31 @@ for f in arm_cfft_radix4_init_q15 arm_bitreversal arm_rfft_init_q15 arm_rfft_ini
   gcc $CFLAGS -c -o "$OUT/$f.o" "$C5/$f.c"
 done
 
-gcc -shared -o "$OUT/libmsdr_ref.so" "$OUT"/arm_fir_fast_q15.o "$OUT"/arm_fir_init_q15.o \
+# (6) the Teensy Audio library's DSP-instruction wrappers (src/Audio/utility/dspinst.h): what AudioFilterBiquad::update
+# (filter_biquad.cpp:54-74) and the front end (mixer.cpp, input_adc.cpp) compute with.  The header carries the Cortex-M4 versions as inline
+# assembly and, for the Cortex-M0+ of a Teensy LC, the SAME functions in plain C behind `#elif defined(KINETISL)` -- for smulwb / smulwt
+# (signed_multiply_32x16b/t), ssat-with-shift (signed_saturate_rshift) and the pkhbt / pkhtb packers.  Those C bodies are compiled here
+# as they stand; the only lines of ours are callers with external linkage (the header's functions are `static inline`).  The
+# multiply-ACCUMULATE forms the biquad uses (smlawb / smlawt, dspinst.h:235-249) exist as assembly only and are not built: the header's
+# own comment defines them as `sum + ((a * b[15:0]) >> 16)`, i.e. the function pinned here plus a 32-bit add.
+{
+  echo '#include <stdint.h>'
+  echo '#define KINETISL'
+  echo "#include \"$REF/src/Audio/utility/dspinst.h\""
+  echo 'int32_t dspinst_signed_multiply_32x16b(int32_t a, uint32_t b) { return signed_multiply_32x16b(a, b); }'
+  echo 'int32_t dspinst_signed_multiply_32x16t(int32_t a, uint32_t b) { return signed_multiply_32x16t(a, b); }'
+  echo 'int32_t dspinst_signed_saturate_rshift(int32_t v, int bits, int rshift) { return signed_saturate_rshift(v, bits, rshift); }'
+  echo 'uint32_t dspinst_pack_16b_16b(int32_t a, int32_t b) { return pack_16b_16b(a, b); }'
+  echo 'uint32_t dspinst_pack_16t_16t(int32_t a, int32_t b) { return pack_16t_16t(a, b); }'
+  echo 'uint32_t dspinst_pack_16t_16b(int32_t a, int32_t b) { return pack_16t_16b(a, b); }'
+} > "$GEN/dspinst_callers.c"
+gcc $CFLAGS -c -o "$OUT/dspinst.o" "$GEN/dspinst_callers.c"
+# (7) arm_sqrt_f32 -- the AM / CW branch's square root on a Teensy 3.6 (Minimal-SDR.ino:611-612) -- is a `static inline` of the reference
+# header itself (arm_math.h:5733-5758: sqrtf for in >= 0, else 0 and ARM_MATH_ARGUMENT_ERROR): a caller with external linkage, as above.
+printf '#include "arm_math.h"\nint cmsis_arm_sqrt_f32(float32_t in, float32_t *pOut) { return (int)arm_sqrt_f32(in, pOut); }\n' \
+  | gcc $CFLAGS -x c -I"$GEN" -I"$C5" -c -o "$OUT/arm_sqrt_f32.o" -
+
+gcc -shared -o "$OUT/libmsdr_ref.so" "$OUT"/dspinst.o "$OUT"/arm_sqrt_f32.o "$OUT"/arm_fir_fast_q15.o "$OUT"/arm_fir_init_q15.o \
     "$OUT"/arm_copy_q15.o "$OUT"/arm_sqrt_q31.o "$OUT"/fir_design.o "$OUT"/fir_design_pid.o \
     "$OUT"/arm_cfft_radix4_q15.o "$OUT"/split_rfft.o "$OUT"/arm_cfft_radix4_init_q15.o "$OUT"/arm_bitreversal.o \
     "$OUT"/arm_rfft_init_q15.o "$OUT"/arm_rfft_init_q31.o "$OUT"/arm_const_structs.o "$OUT"/arm_common_tables.o -lm

@@ -168,6 +168,10 @@ int orc_sqrt_q31(q31_t in, q31_t *out)
  * Out-of-range float->int16 (only reachable with |I|,|Q| > 23170 together) is taken as
  * convert-to-int32-then-truncate, which is what both ARM (vcvt + strh) and x86 do.
  * ====================================================================================== */
+/* arm_sqrt_f32, arm_math.h:5733-5758: sqrtf for in >= 0, else 0 (and ARM_MATH_ARGUMENT_ERROR, which the sketch ignores, .ino:612).
+ * Pinned against the header's own inline (oracle/build_ref.sh step 7) through the hook below. */
+static inline float am_sqrt_f32(float f) { return (f >= 0.0f) ? sqrtf(f) : 0.0f; }
+float orc_prim_sqrt_f32(float in) { return am_sqrt_f32(in); }
 void orc_demod_q15(int mode, int sqrt_kind, const int16_t *I, const int16_t *Q,
                    int16_t *out, uint32_t n)
 {
@@ -183,7 +187,7 @@ void orc_demod_q15(int mode, int sqrt_kind, const int16_t *I, const int16_t *Q,
                 out[i] = (int16_t)(r >> 16);
             } else {
                 float f = (float)s;
-                float r = (f >= 0.0f) ? sqrtf(f) : 0.0f;
+                float r = am_sqrt_f32(f);
                 out[i] = (int16_t)(uint16_t)(uint32_t)(int32_t)r;
             }
         } break;
@@ -249,6 +253,15 @@ ORC_CLONES void orc_fir_f32(const orc_fir_instance_f32 *S, const float *pSrc, fl
  * the whole block; bit 31 of word 7 says another stage follows.   PARITY UNPINNED.
  * ====================================================================================== */
 static inline int32_t mulw16(int32_t coef, int16_t s) { return (int32_t)(((int64_t)coef * s) >> 16); }
+/* Test hooks: the two primitives above exactly as the biquad, the amplifier and the DC blocker below use them, so that
+ * tests/test_oracle_pinned.py can hold them against the reference's own plain-C bodies (dspinst.h, KINETISL branch, compiled by
+ * oracle/build_ref.sh): smulwb / smulwt = mulw16 on the bottom / top half-word, ssat #16 with asr = ssat16(v >> rshift). */
+int32_t orc_prim_mulw16b(int32_t a, uint32_t b) { return mulw16(a, (int16_t)(b & 0xFFFFu)); }
+int32_t orc_prim_mulw16t(int32_t a, uint32_t b) { return mulw16(a, (int16_t)(b >> 16)); }
+int32_t orc_prim_ssat16_rshift(int32_t v, int rshift) { return ssat16(v >> rshift); }
+/* history words 5 / 6 of a stage record: the newer sample in the top half (filter_biquad.cpp:72-73: pack_16b_16b(newer, older)) */
+static inline int32_t pack_hist(int16_t newer, int16_t older) { return (int32_t)(((uint32_t)(uint16_t)newer << 16) | (uint16_t)older); }
+uint32_t orc_prim_pack_hist(int32_t newer, int32_t older) { return (uint32_t)pack_hist((int16_t)newer, (int16_t)older); }
 
 void orc_biquad_teensy_init(orc_biquad_teensy *b) { memset(b->definition, 0, sizeof b->definition); }
 
@@ -287,8 +300,8 @@ void orc_biquad_teensy_update(orc_biquad_teensy *b, int16_t *data, uint32_t n)
             data[i] = y0;
         }
         flag = (uint32_t)st[7] & 0x80000000u;
-        st[5] = (int32_t)(((uint32_t)(uint16_t)x1 << 16) | (uint16_t)x2);
-        st[6] = (int32_t)(((uint32_t)(uint16_t)y1 << 16) | (uint16_t)y2);
+        st[5] = pack_hist(x1, x2);
+        st[6] = pack_hist(y1, y2);
         st[7] = (int32_t)((uint32_t)res | flag);
         st += 8;
     } while (flag);

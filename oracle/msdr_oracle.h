@@ -9,11 +9,16 @@
  * Pinning status (see DESIGN.md "Oracle"):
  *   PINNED   against oracle/_ref/libmsdr_ref.so (the reference's own sources compiled here by
  *            oracle/build_ref.sh): orc_fir_init_q15, orc_fir_fast_q15, orc_copy_q15,
- *            orc_sqrt_q31, orc_calc_fir_coeffs, orc_izero, orc_m_sinc.
+ *            orc_sqrt_q31, orc_calc_fir_coeffs, orc_izero, orc_m_sinc; the q15 FFT stages (row f4); arm_sqrt_f32 as the
+ *            AM branch calls it (a static inline of arm_math.h, orc_prim_sqrt_f32);
+ *            the arithmetic PRIMITIVES of orc_biquad_teensy_*, orc_amp_* and the DC blocker -- mulw16 on either
+ *            half-word, ssat16(v >> s), the history-word packing -- against the plain-C bodies dspinst.h itself
+ *            carries for the Cortex-M0+ (src/Audio/utility/dspinst.h:34-51, :70-92, :151-184; orc_prim_* below).
  *   UNPINNED ("parity unpinned": the reference code cannot be built here without stand-ins for
  *            the un-vendored Teensyduino core / ARM inline asm, or has no source at all):
  *            orc_mix_fs4_q15, orc_freqconv_q15 (+ orc_mult/add/sub_q15), orc_demod_q15,
- *            orc_biquad_teensy_*, and every *_f32 function (arm_fir_f32 and
+ *            the loop of orc_biquad_teensy_* (its multiply-accumulate wrappers smlawb / smlawt are assembly only,
+ *            dspinst.h:235-249, and filter_biquad.cpp needs the Teensy core), and every *_f32 function (arm_fir_f32 and
  *            arm_biquad_cascade_df1_f32 are prototypes only in the reference:
  *            src/CMSIS_5/arm_math.h:1182-1202, :1333-1351; module CMSIS-DSP V1.5.x).
  */
@@ -180,6 +185,12 @@ typedef struct { int32_t hpf_y1, hpf_x1; } orc_dcblock;                 /* input
 void orc_dcblock_init(orc_dcblock *s, uint16_t first_conversion);          /* input_adc.cpp:60-63 */
 /* adc: raw unsigned 16-bit conversions; out: the block AudioInputAnalog transmits */
 void orc_dcblock_update(orc_dcblock *s, const uint16_t *adc, int16_t *out, uint32_t n);
+/* test hooks: the oracle's smulwb / smulwt / ssat-asr primitives (pinned against dspinst.h's own C bodies) */
+int32_t orc_prim_mulw16b(int32_t a, uint32_t b);
+int32_t orc_prim_mulw16t(int32_t a, uint32_t b);
+int32_t orc_prim_ssat16_rshift(int32_t v, int rshift);
+uint32_t orc_prim_pack_hist(int32_t newer, int32_t older);
+float orc_prim_sqrt_f32(float in);                                         /* the AM branch's arm_sqrt_f32 (arm_math.h:5733-5758) */
 int32_t orc_amp_multiplier(float gain);                                    /* AudioAmplifier::gain, mixer.h:75-79 */
 /* AudioAmplifier::update, mixer.cpp:134-159: returns 0 when nothing is transmitted (multiplier 0), else 1; in place */
 int orc_amp_update(int32_t multiplier, int16_t *data, uint32_t n);

@@ -201,3 +201,87 @@ def test_spectrum_tick_cadence(orc):
     hits = [i for i in range(80) if orc.lib.orc_spectrum_tick(1, C.byref(cnt))]
     assert hits == [0, 25, 50, 75]
     assert orc.lib.orc_spectrum_tick(0, C.byref(cnt)) == 0
+
+
+# ---------------------------------------------------------------- A7 / f1: the arithmetic primitives ---------
+# AudioFilterBiquad::update (filter_biquad.cpp:54-74) and the front end are built from the DSP-instruction wrappers of
+# src/Audio/utility/dspinst.h.  The header carries them as Cortex-M4 inline assembly AND, for the Cortex-M0+, as plain C
+# (`#elif defined(KINETISL)`): oracle/build_ref.sh compiles those C bodies as they stand.  The oracle's mulw16 / ssat16(v >> s) /
+# history packing -- what its biquad, amplifier and DC blocker are made of -- must equal them on every input.
+def _prims(orc):
+    import ctypes as C
+    L = orc.lib
+    for n in ("orc_prim_mulw16b", "orc_prim_mulw16t"):
+        getattr(L, n).restype = C.c_int32
+        getattr(L, n).argtypes = [C.c_int32, C.c_uint32]
+    L.orc_prim_ssat16_rshift.restype = C.c_int32
+    L.orc_prim_ssat16_rshift.argtypes = [C.c_int32, C.c_int]
+    L.orc_prim_pack_hist.restype = C.c_uint32
+    L.orc_prim_pack_hist.argtypes = [C.c_int32, C.c_int32]
+    return L
+
+
+def test_dspinst_primitives_match_golden(orc):
+    import hashlib
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(here, "dspinst_prims.npz"))
+    want_sha = json.load(open(os.path.join(here, "dspinst_prims.sha256.json")))
+    assert sorted(g.files) == sorted(want_sha)
+    for k in g.files:
+        assert hashlib.sha256(np.ascontiguousarray(g[k]).tobytes()).hexdigest() == want_sha[k], k
+    L = _prims(orc)
+    a, b = g["a"], g["b"]
+    assert a.size > 20000
+    for i in range(a.size):
+        x, y = int(a[i]), int(b[i]) & 0xFFFFFFFF
+        assert L.orc_prim_mulw16b(x, y) == int(g["mulwb"][i]), (x, y)
+        assert L.orc_prim_mulw16t(x, y) == int(g["mulwt"][i]), (x, y)
+        for sh in (0, 14, 15):
+            assert L.orc_prim_ssat16_rshift(x, sh) == int(g["ssat16_asr%d" % sh][i]), (x, sh)
+        # pack_16b_16b(a, b) = (a[15:0] << 16) | b[15:0]: the oracle packs (newer, older) history the same way
+        assert L.orc_prim_pack_hist(x, int(b[i])) == int(g["pack_bb"][i]), (x, y)
+
+
+def test_dspinst_primitives_match_reference_live(orc, ref):
+    import ctypes as C
+    L, R = _prims(orc), ref.lib
+    for n in ("dspinst_signed_multiply_32x16b", "dspinst_signed_multiply_32x16t"):
+        getattr(R, n).restype = C.c_int32
+        getattr(R, n).argtypes = [C.c_int32, C.c_uint32]
+    R.dspinst_signed_saturate_rshift.restype = C.c_int32
+    R.dspinst_signed_saturate_rshift.argtypes = [C.c_int32, C.c_int, C.c_int]
+    R.dspinst_pack_16b_16b.restype = C.c_uint32
+    R.dspinst_pack_16b_16b.argtypes = [C.c_int32, C.c_int32]
+    rng = np.random.default_rng(77)
+    a = rng.integers(-2 ** 31, 2 ** 31, 30000).astype(np.int32)
+    b = rng.integers(-2 ** 31, 2 ** 31, 30000).astype(np.int32)
+    a[:8] = [0x7FFFFFFF, -0x80000000, 0x40000000, -0x40000000, -1, 1, 0x3FFF, -0x4000]
+    b[:8] = [-0x80000000, 0x7FFFFFFF, 0x80008000 - (1 << 32), 0x7FFF7FFF, -1, 0x00010001, 0x8000, 0x7FFF]
+    for x, y in zip(a, b):
+        x, yu = int(x), int(y) & 0xFFFFFFFF
+        assert L.orc_prim_mulw16b(x, yu) == R.dspinst_signed_multiply_32x16b(x, yu)
+        assert L.orc_prim_mulw16t(x, yu) == R.dspinst_signed_multiply_32x16t(x, yu)
+        for sh in (0, 1, 14, 15, 16):
+            assert L.orc_prim_ssat16_rshift(x, sh) == R.dspinst_signed_saturate_rshift(x, 16, sh)
+        assert L.orc_prim_pack_hist(x, int(y)) == R.dspinst_pack_16b_16b(x, int(y))
+
+
+def test_am_sqrt_f32_matches_reference_live(orc, ref):
+    """arm_sqrt_f32 (a static inline of the reference's arm_math.h, :5733-5758) as the Teensy-3.6 AM / CW branch calls it (Minimal-SDR.ino:611-612):
+    every int32 the sum I*I + Q*Q can take goes through (float): negative sums (int overflow at full scale) give 0, not NaN."""
+    import ctypes as C
+    orc.lib.orc_prim_sqrt_f32.restype = C.c_float
+    orc.lib.orc_prim_sqrt_f32.argtypes = [C.c_float]
+    ref.lib.cmsis_arm_sqrt_f32.restype = C.c_int
+    ref.lib.cmsis_arm_sqrt_f32.argtypes = [C.c_float, C.POINTER(C.c_float)]
+    rng = np.random.default_rng(5)
+    vals = np.concatenate([rng.integers(-2 ** 31, 2 ** 31, 20000).astype(np.float32), np.arange(0, 4096, dtype=np.float32) ** 2,
+                           np.array([0.0, -0.0, 1e-45, -1e-45, 2147483648.0, -2147483648.0, 2.0 * 32768.0 ** 2, np.inf], np.float32)])
+    for v in vals:
+        out = C.c_float(-1.0)
+        rc = ref.lib.cmsis_arm_sqrt_f32(float(v), C.byref(out))
+        got = orc.lib.orc_prim_sqrt_f32(float(v))
+        assert np.float32(got).tobytes() == np.float32(out.value).tobytes(), float(v)
+        assert rc == (0 if v >= 0 else -1)

@@ -770,9 +770,10 @@ struct msdr_fir_f32 : FirInst<float, float> {
     unsigned *d_tq_ctr = nullptr;
     int tq_flip = 0, tq_fronts = 32;     // 32 fronts: 24 ... 64 within 1 %, 16 and fewer saturate the counters (profiles/r03/fir_ab.txt)
     // tiles per draw = 2^shift (round 4): the second .. last tile of a run take their 1 KB halo from the registers that hold the tile before.
-    // Runs of 4: HBM traffic / algorithmic 1.049 -> 1.01, a fifth of the loads gone; time -0.5 % only (the kernel sits at the power cap: the
-    // clock rises by what the traffic saves), runs of 2 / 8 the same (profiles/r04/README.md).  MSDR_TQ_RUN_SHIFT overrides (tests: 0 .. 3).
-    int tq_run_shift_cap = getenv("MSDR_TQ_RUN_SHIFT") ? std::max(0, std::min(6, atoi(getenv("MSDR_TQ_RUN_SHIFT")))) : 2;
+    // Runs of 4 / 8: HBM traffic / algorithmic 1.049 -> 1.037 / ~1.02 (the halos that are still fetched all miss L2), a fifth of the loads gone;
+    // time -0.5 % only (the kernel sits at the power cap: the clock rises by what the traffic saves), runs of 2 .. 8 alike
+    // (profiles/r04/README.md).  MSDR_TQ_RUN_SHIFT overrides (tests: 0 .. 3).
+    int tq_run_shift_cap = getenv("MSDR_TQ_RUN_SHIFT") ? std::max(0, std::min(6, atoi(getenv("MSDR_TQ_RUN_SHIFT")))) : 3;
     bool tq_run_forced = getenv("MSDR_TQ_RUN_SHIFT") != nullptr;       // (the override also lifts the "every wave gets >= 16 runs" rule: small test shapes reach the run code)
     float input_range = 0.0f;            // 0 = block floating point per tile (default); > 0: a fixed scale for samples below this magnitude
 };
@@ -1039,10 +1040,11 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
         q.ctr_next = S->d_tq_ctr + (size_t)(S->tq_flip ^ 1) * kTqMaxFronts * kTqCtrStride;
         q.all_aligned = ((blockSize & 3u) == 0 && (reinterpret_cast<uintptr_t>(d_src) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_dst) & 15) == 0) ? 1 : 0;
         const unsigned grid = std::max(want, q.fronts);
-        // runs of consecutive tiles per draw (the halo of the second .. last comes from registers): as long as every wave still gets >= 16 runs
+        // runs of consecutive tiles per draw (the halo of the second .. last comes from registers): as long as every wave still gets >= 64 runs
+        // (the queue's tail is one run per wave at most)
         q.run_shift = 0;
         { const int cap = S->tq_run_shift_cap;
-          while (q.run_shift < cap && (q.tpr >> (q.run_shift + 1)) >= 1 && (S->tq_run_forced || (long long)q.total >= (long long)grid * 4 * 16 * (2LL << q.run_shift))) q.run_shift++; }
+          while (q.run_shift < cap && (q.tpr >> (q.run_shift + 1)) >= 1 && (S->tq_run_forced || (long long)q.total >= (long long)grid * 4 * 64 * (2LL << q.run_shift))) q.run_shift++; }
         const size_t lds = 4 * tr_wave_bytes(S->tr_ns);
 #define MSDR_TQ_LAUNCH(NS_) case NS_: \
             if (S->tr_skip1) hipLaunchKernelGGL((fir_f32tq_kernel<NS_, true>), dim3(grid), dim3(256), lds, S->ctx->stream, q); \

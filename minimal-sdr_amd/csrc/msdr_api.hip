@@ -774,6 +774,7 @@ struct msdr_fir_f32 : FirInst<float, float> {
     // time -0.5 % only (the kernel sits at the power cap: the clock rises by what the traffic saves), runs of 2 .. 8 alike
     // (profiles/r04/README.md).  MSDR_TQ_RUN_SHIFT overrides (tests: 0 .. 3).
     int tq_run_shift_cap = getenv("MSDR_TQ_RUN_SHIFT") ? std::max(0, std::min(6, atoi(getenv("MSDR_TQ_RUN_SHIFT")))) : 3;
+    int last_launch = 0;                 // what the last msdr_fir_f32_process launched: 0 none yet, 1 tile queue, 2 fir_f32mf_kernel (the name follows the size guard)
     bool tq_run_forced = getenv("MSDR_TQ_RUN_SHIFT") != nullptr;       // (the override also lifts the "every wave gets >= 16 runs" rule: small test shapes reach the run code)
     float input_range = 0.0f;            // 0 = block floating point per tile (default); > 0: a fixed scale for samples below this magnitude
 };
@@ -1058,7 +1059,7 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
         } }
 #undef MSDR_TQ_LAUNCH
         if (int rc = launch_check("fir_f32tq_kernel")) return rc;
-        S->tq_flip ^= 1;
+        S->tq_flip ^= 1; S->last_launch = 1;
         hipLaunchKernelGGL((history_kernel<float>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
                            d_src, (const float *)S->d_hist[S->cur], S->d_hist[S->cur ^ 1], (long long)blockSize, (int)S->hist_len, (int)S->channels);
         if (int rc = launch_check("history_kernel")) return rc;
@@ -1079,6 +1080,7 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
                        (const float *)S->d_hist[S->cur], (const char *)S->d_fm_tab, (long long)blockSize, (int)S->channels, (int)nseg, seg_len,
                        (int)S->hist_len, H, ns, nw); }
     if (int rc = launch_check("fir_f32mf_kernel")) return rc;
+    S->last_launch = 2;
     hipLaunchKernelGGL((history_kernel<float>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
                        d_src, (const float *)S->d_hist[S->cur], S->d_hist[S->cur ^ 1], (long long)blockSize, (int)S->hist_len, (int)S->channels);
     if (int rc = launch_check("history_kernel")) return rc;
@@ -1105,7 +1107,8 @@ extern "C" const char *msdr_fir_f32_kernel_name(msdr_fir_f32 *S)
 {
     static thread_local char name[64];
     if (!S) return "";
-    if (S->d_tr_tab && S->d_tq_ctr) snprintf(name, sizeof name, "fir_f32tq_kernel<%d, %s>", S->tr_ns, S->tr_skip1 ? "true" : "false");
+    // (a call whose tile count does not fit the queue's 32-bit index runs the stream kernel: after a call the name is the launched one)
+    if (S->d_tr_tab && S->d_tq_ctr && S->last_launch != 2) snprintf(name, sizeof name, "fir_f32tq_kernel<%d, %s>", S->tr_ns, S->tr_skip1 ? "true" : "false");
     else snprintf(name, sizeof name, "%s", S->d_fm_tab ? "fir_f32mf_kernel" : "fir_kernel<FirF32>");
     return name;
 }

@@ -8,4 +8,5 @@ case ${1:-a} in
   a) run fuzz_kernels 280 4101; run fuzz_live 240 4102; run fuzz_fir_f32 200 4103 ;;
   b) run fuzz_retune 150 4104; run fuzz_retune_q15 150 4105; run fuzz_f32_truth 240 4106; run fuzz_stage_df1 120 4107 ;;
   c) run fuzz_pll_anr 120 4108; run fuzz_pll_anr_f32 120 4109; run fuzz_frontend 120 4110; run fuzz_kernels 280 4111 ;;
+  d) run fuzz_kernels 300 4201; run fuzz_live 300 4202; run fuzz_f32_truth 300 4206 ;;     # a second pass with fresh seeds at the round's last revision
 esac

@@ -5,7 +5,10 @@ visible fraction of what is left of the signal, and two correct fp32 evaluations
 nothing unless |gpu - oracle| exceeds the 1e-5 tolerance; then it compares both with the float64 result:
     e_gpu = |gpu - f64| / |f64|      e_orc = |oracle - f64| / |f64|
 A case counts as a DEFECT only if the library is further from the float64 result than the contract of include/msdr.h allows
-(e_gpu > 2 e_orc + fp32_noise + 1e-6, fp32_noise = the cascade's own figure from msdr_biquad_df1_f32_cascade_info).
+(e_gpu > 2 e_orc + fp32_noise + 1e-6 lvl, fp32_noise = the cascade's own figure from msdr_biquad_df1_f32_cascade_info; lvl = the level of the
+cascade's INPUT over its output, >= 1: where the cascade removes most of its input -- a constant envelope behind a high-pass: two taps and a
+sign-only input do that -- the 1e-5 / 1e-6 of the contract refer to the input's level; round 4's seed 4206 drew five such cases, judged as
+defects by this script's first version, which lacked the clause: tests/test_gpu_f32_contract.py holds them now).
 Each case draws from default_rng([seed, case])."""
 import os, sys, time
 import numpy as np
@@ -39,7 +42,7 @@ def truth64(x, mode, hi, hq, oi, oq, bq):
 
 
 t_end = time.time() + budget
-case = over = defects = 0
+case = over = defects = attenuating = 0
 worst = 0.0
 while time.time() < t_end:
     case += 1
@@ -87,14 +90,19 @@ while time.time() < t_end:
         if e_go < 1e-5 and only < 0:
             continue
         over += 1
+        pre = orc.chain_f32(x[c], modes[c], hi, hq, oi, oq, None)             # the cascade's input
+        lvl = max(1.0, float(np.sqrt((pre.astype(np.float64) ** 2).mean() / max((want.astype(np.float64) ** 2).mean(), 1e-300))))
+        if e_go < 1e-5 * lvl and only < 0:
+            attenuating += 1
+            continue
         t = truth64(x[c], int(modes[c]), hi, hq, oi, oq, bq)
         e_gpu, e_orc = rel_rms(got[c], t), rel_rms(want, t)
         worst = max(worst, e_gpu / max(e_orc, 1e-12))
-        bad = e_gpu > 2 * e_orc + msdr.biquad_cascade_info(bq)[1] + 1e-6       # the contract of include/msdr.h (fp32_noise: the cascade's own figure)
+        bad = e_gpu > 2 * e_orc + msdr.biquad_cascade_info(bq)[1] + 1e-6 * lvl  # the contract of include/msdr.h (fp32_noise: the cascade's own figure; lvl: its input's level)
         defects += bad
         print("%s case %d: gpu-oracle %.2e | gpu-f64 %.2e  oracle-f64 %.2e | taps %d stages %d P %d mixer %d mode %d %s n %d segs %d"
               % ("DEFECT" if bad else "inherent", case, e_go, e_gpu, e_orc, ntaps, stages, P, mixer, int(modes[c]), chain.info()["kernel"], n,
                  chain.info()["time_segments"]), flush=True)
     chain.close()
-print("fuzz_f32_truth done: %d cases, %d over 1e-5 vs the fp32 oracle, %d of them further from float64 than the oracle is (worst e_gpu/e_orc %.2f), seed %d"
-      % (case, over, defects, worst, seed))
+print("fuzz_f32_truth done: %d cases, %d over 1e-5 vs the fp32 oracle: %d within 1e-5 of the cascade's input level, %d of the others beyond the contract against float64 (worst e_gpu/e_orc %.2f), seed %d"
+      % (case, over, attenuating, defects, worst, seed))

@@ -112,9 +112,12 @@ def test_fp32_contract_on_the_fuzzers_cases(ctx, orc):
     seed 4106 (round 4's run): the two cases that run flagged -- 46411, four sections whose numerators-first ORDER alone costs 11 x the
     sequential order's noise (kappa 15: every older criterion passed; the library now runs it in CMSIS order), and 34917, three resonant high-pass
     sections (kappa 7e5, fp32_noise 1e-5) that the library already runs in CMSIS order: the same arithmetic as the oracle's on an input that
-    agrees to 5e-7 -- 1.1e-5 from float64 where the oracle is 4.4e-6 (the contract's fp32_noise term)."""
+    agrees to 5e-7 -- 1.1e-5 from float64 where the oracle is 4.4e-6 (the contract's fp32_noise term); seed 4206 (round 4's second pass): the five cases
+    the fuzzer's first judge flagged -- two taps and a sign-only input give a CONSTANT envelope, the cascade's high-pass removes it, and what is left
+    of the library's 2e-7 rounding noise (the oracle's envelope has 5 distinct values, the tiled evaluation 32) is 1.3e-5 of a decayed transient:
+    the contract's input-level clause."""
     stats = dict(checks=0, over=0, worst=0.0, attenuating=0)
-    for seed, cases in ((2026, list(range(1, 151)) + [39938]), (88, range(1, 26)), (911, range(1, 26)), (4106, [46411, 34917])):
+    for seed, cases in ((2026, list(range(1, 151)) + [39938]), (88, range(1, 26)), (911, range(1, 26)), (4106, [46411, 34917]), (4206, [9392, 12427, 16133, 19455])):
         for case in cases:
             _judge(ctx, orc, _case(orc, seed, case), (seed, case), stats)
     print("fp32 contract: %d channel checks, %d beyond 1e-5 of the fp32 oracle: %d within 1e-5 of the cascade's input level, the others judged against float64 (worst e_gpu / e_orc %.2f)"

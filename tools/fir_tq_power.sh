@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 mkdir -p gpurun_out
 OUT=gpurun_out/fir_tq_power.txt
 : > $OUT
-for v in 0 1 2 3 8 24 10; do
+for v in ${VARIANTS:-0 1 2 3 8 24 10}; do
   ./tools/probes/fir_tq_bench 32 $v ${SECS:-7} > gpurun_out/fir_tq_power_$v.json 2>&1 &
   BP=$!
   sleep 3
@@ -17,6 +17,6 @@ for v in 0 1 2 3 8 24 10; do
   wait $BP
   cat gpurun_out/fir_tq_power_$v.json >> $OUT
 done
-./tools/probes/fir_tq_bench 32 > gpurun_out/fir_tq_fastfir.jsonl 2>&1
+[ -n "${VARIANTS:-}" ] || ./tools/probes/fir_tq_bench 32 > gpurun_out/fir_tq_fastfir.jsonl 2>&1
 cat $OUT
 cat gpurun_out/fir_tq_fastfir.jsonl

@@ -16,6 +16,8 @@
 #include "msdr_fir_f32tr.hiph"
 #include "msdr_fir_f32tq.hiph"
 #include "msdr_chain_amtr.hiph"
+#include "msdr_chain_mfb.hiph"
+#include "msdr_block.h"
 #include "msdr_design.h"
 #include "msdr_cascade_state.h"
 
@@ -1968,6 +1970,13 @@ struct msdr_chain {
     uint64_t mode_gen, units_mode_gen;
     long long units_nseg;
     uint32_t units_wgs;
+    // block cadence (msdr_chain_mfb.hiph): tile table (channels per tile, grouped by table set; SSB-table part first), cached per (modes, n)
+    int *d_btiles = nullptr;
+    size_t btiles_cap = 0;
+    uint64_t btiles_mode_gen = 0;
+    long long btiles_n = -1;
+    struct BlockPart { uint32_t wgs = 0, nw = 0, tpw = 0; size_t offset = 0; } bpart[2];
+    bool block_off = false;              // MSDR_NO_BLOCK=1 at create time: keep the wave-stream kernels at every call length (A/B runs, tests)
     std::vector<std::vector<float>> h_coef_i, h_coef_q;   // host copies for msdr_chain_set_mode
     std::vector<double> h_osc, h_cnum;                    // oscillator pairs {cos, sin}; combined numerator
     struct DHist { double v[8]; };
@@ -2041,7 +2050,7 @@ static void chain_free(msdr_chain *c)
     hipFree(c->d_anr_on);
     for (auto &e : c->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &o : c->osc_pending) hipFree(o.d_tab);
-    hipFree(c->d_f32_scratch); hipFree(c->d_osc_hist);
+    hipFree(c->d_f32_scratch); hipFree(c->d_osc_hist); hipFree(c->d_btiles);
     delete c;
 }
 
@@ -2119,6 +2128,7 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
     c->pole_radius = c->nstages ? max_pole_radius(cfg->biquad_coeffs, (int)c->nstages) : 0.0;
     c->cur = 0; c->phase = 0; c->timing = false; c->timed_ms = 0; c->timed_launches = 0;
     c->gen = 1; c->dh_cache.resize(c->channels); c->dh_gen.assign(c->channels, 0);
+    c->block_off = getenv("MSDR_NO_BLOCK") != nullptr;
     c->flags = cfg->flags; c->mfw_nw = 0; c->mfw_waves_per_cu = 0; c->d_bq_state_alt = nullptr; c->d_mw_iir = nullptr; c->d_units = nullptr; c->units_cap = 0;
     c->mode_gen = 1; c->units_mode_gen = 0; c->units_nseg = 0; c->units_wgs = 0; c->units_wgs_ssb = 0; c->mfw_ssb_fold = false; c->mfw_am_fold = false; c->units_tiles = -1;
     c->part_nseg[0] = c->part_nseg[1] = 1; c->part_seg_len[0] = c->part_seg_len[1] = 0;
@@ -2966,6 +2976,16 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         for (int ts : c->h_tapset) if (!c->qm_set_ok[ts]) { use_qm = false; break; }      // a tap >= 32640: the VALU kernel runs
     if (use_mf) use_fold = false;
     const int kTile = use_mfw ? kMwTile : use_fold ? kFoldTile : kChainTile;
+    // ---- block cadence (msdr_chain_mfb.hiph): one AUDIO_BLOCK (or another short block) per call -- channel-batched tiles, the next
+    // history written by the kernel itself.  Taken where the wave-stream kernel would run its folded flavours (or no cascade at all).
+    bool use_mfb = false;
+    if (use_mfw && !c->block_off && !c->mf_fr && c->nstages <= 2 && mb_n_ok((long long)n_samples) && (int)c->hist_len == c->mf_halo &&
+        (reinterpret_cast<uintptr_t>(d_if) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 &&
+        mb_lds_bytes(c->mf_halo, (int)n_samples, c->mf_bsteps, 1) <= 160 * 1024) {
+        bool need_ssb = false, need_env = false;
+        for (int m : c->h_mode) { if (m == MSDR_MODE_LSB || m == MSDR_MODE_USB) need_ssb = true; else need_env = true; }
+        use_mfb = c->nstages == 0 || ((!need_ssb || c->mfw_ssb_fold) && (!need_env || c->mfw_am_fold));
+    }
     p.mf_tab = c->d_mf_tab; p.mf_stride = c->mf_stride; p.mf_halo = c->mf_halo; p.mf_bsteps = c->mf_bsteps; p.bq_mf = c->d_bq_mf; p.bq_mf32 = c->d_bq_mf32;
     const int osc_P = use_mf ? c->mf_P : c->fold_P;            // the matrix-core tables exist for periods up to 32, the VALU fold tables up to 4
     p.ftaps = c->d_ftaps; p.chan_fset = c->d_fset; p.fold_period = osc_P; p.bq_fold = c->d_bq_fold;
@@ -3015,6 +3035,76 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     p.nseg = (int)nseg; p.seg_len = seg_tiles * kTile; p.warm = (int)(nseg > 1 ? warm_tiles * kTile : 0);
 
     unsigned grid = (unsigned)(c->channels * nseg);
+    if (use_mfb) {
+        // tile table: CPT channels per tile, channels grouped by table set (SSB tables first, envelope tables after: two launches of two
+        // kernels); a workgroup = nw waves x tpw tiles of ONE table set, a group's tiles dealt round-robin to the waves, idle slots = -1
+        const int n_ = (int)n_samples, cpt = mb_cpt(n_);
+        if (c->btiles_mode_gen != c->mode_gen || c->btiles_n != (long long)n_samples) {
+            std::vector<uint32_t> order(c->channels);
+            for (uint32_t i = 0; i < c->channels; i++) order[i] = i;
+            auto fset_of = [&](uint32_t ch) { const int m = c->h_mode[ch]; return c->h_tapset[ch] * 3 + (m == MSDR_MODE_LSB ? 0 : m == MSDR_MODE_USB ? 1 : 2); };
+            auto env_of = [&](uint32_t ch) { return fset_of(ch) % 3 == 2 ? 1 : 0; };
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return env_of(a) * 1000000 + fset_of(a) < env_of(b) * 1000000 + fset_of(b); });
+            std::vector<int> tab;
+            size_t i0 = 0;
+            for (int part = 0; part < 2; part++) {
+                // the part's groups and tile count
+                std::vector<std::pair<size_t, size_t>> groups;          // [begin, end) in `order`
+                size_t i = i0;
+                long long tiles_part = 0;
+                while (i < order.size() && env_of(order[i]) == part) {
+                    size_t j = i;
+                    while (j < order.size() && fset_of(order[j]) == fset_of(order[i])) j++;
+                    groups.emplace_back(i, j);
+                    tiles_part += (long long)((j - i) + cpt - 1) / cpt;
+                    i = j;
+                }
+                i0 = i;
+                msdr_chain::BlockPart &bp = c->bpart[part];
+                bp = msdr_chain::BlockPart();
+                bp.offset = tab.size();
+                if (tiles_part == 0) continue;
+                // waves per workgroup / tiles per wave: the fewest tiles per SIMD (a workgroup's waves spread over the CU's four SIMDs),
+                // ties to fewer waves; one workgroup per CU at these LDS sizes
+                int nwmax = 1;
+                while (nwmax < 8 && mb_lds_bytes(c->mf_halo, n_, c->mf_bsteps, nwmax + 1) <= 160 * 1024) nwmax++;
+                long long best_cost = -1;
+                for (int w = 1; w <= nwmax; w++) {
+                    const long long tpw = (tiles_part + (long long)c->ctx->num_cus * w - 1) / ((long long)c->ctx->num_cus * w);
+                    const long long cost = tpw * ((w + 3) / 4);
+                    if (best_cost < 0 || cost < best_cost) { best_cost = cost; bp.nw = (uint32_t)w; bp.tpw = (uint32_t)tpw; }
+                }
+                const size_t per_wg = (size_t)bp.nw * bp.tpw;
+                for (auto &g : groups) {
+                    const size_t tiles_g = ((g.second - g.first) + cpt - 1) / cpt;
+                    for (size_t t0 = 0; t0 < tiles_g; t0 += per_wg) {
+                        const size_t base = tab.size();
+                        tab.resize(base + per_wg * cpt, -1);
+                        const size_t cnt = std::min(per_wg, tiles_g - t0);
+                        for (size_t t = 0; t < cnt; t++) {           // tile t of this workgroup -> wave t % nw, its slot t / nw
+                            const size_t slot = (t % bp.nw) * bp.tpw + t / bp.nw;
+                            for (int k = 0; k < cpt; k++) {
+                                const size_t idx = g.first + (t0 + t) * cpt + k;
+                                if (idx < g.second) tab[base + slot * cpt + k] = (int)order[idx];
+                            }
+                        }
+                        bp.wgs++;
+                    }
+                }
+            }
+            if (tab.size() > c->btiles_cap) {
+                HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+                hipFree(c->d_btiles); c->d_btiles = nullptr; c->btiles_cap = 0;
+                if (int rc = dzalloc(c->ctx, tab.size(), &c->d_btiles)) return rc;
+                c->btiles_cap = tab.size();
+            }
+            HIP_TRY(hipMemcpyAsync(c->d_btiles, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));
+            HIP_TRY(hipStreamSynchronize(c->ctx->stream));        // `tab` is a local
+            c->btiles_mode_gen = c->mode_gen; c->btiles_n = (long long)n_samples;
+        }
+        nseg = 1; p.nseg = 1; p.warm = 0;
+        p.bq_state_out = c->d_bq_state_alt; p.mw_iir = c->d_mw_iir;
+    } else
     if (use_mfw) {
         // unit table: (channel, segment) per wave; the waves of a workgroup share one tap table, so channels are grouped by
         // table set and every group is padded to whole workgroups.  SSB-table units and envelope-table units are two launches
@@ -3077,6 +3167,24 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     }
     const char *kname = f32 ? "chain_kernel<ArithF32>" : "chain_kernel<ArithQ15>";
     unsigned block = kThreads;
+    size_t lds_used = lds;
+    if (use_mfb) {
+        static const char *const names[3] = {"chain_mfb_kernel<0> (channel-batched block tiles)", "chain_mfb_kernel<1> (channel-batched block tiles)",
+                                             "chain_mfb_kernel<2> (channel-batched block tiles)"};
+        grid = 0;
+        for (int part = 0; part < 2; part++) {
+            const msdr_chain::BlockPart &bp = c->bpart[part];
+            if (bp.wgs == 0) continue;
+            ChainParams q = p;
+            q.mf_units = c->d_btiles + bp.offset; q.mf_nw = (int)bp.nw; q.nseg = (int)bp.tpw;
+            lds_used = mb_lds_bytes(c->mf_halo, (int)n_samples, c->mf_bsteps, (int)bp.nw);
+            if (launch_chain_mfb(c->ctx->stream, (int)c->nstages, part == 1, bp.wgs, bp.nw * 64, lds_used, q) != hipSuccess)
+                return fail(MSDR_STATUS_HIP_ERROR, "chain_mfb_kernel launch failed");
+            grid += bp.wgs; block = bp.nw * 64;
+        }
+        kname = names[c->nstages];
+        if (c->nstages > 0) std::swap(c->d_bq_state, c->d_bq_state_alt);      // the kernel read bq_state and wrote bq_state_out
+    } else
     if (use_mfw) {
         block = (unsigned)c->mfw_nw * 64;
         // SSB-table units and envelope-table units are separate launches of separate kernels (register allocation per flavour)
@@ -3249,10 +3357,12 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         if (int rc = launch_check("f32_to_q15_kernel")) return rc;
     }
 
-    hipLaunchKernelGGL((history_kernel<int16_t>), dim3(grid_1d((long long)c->channels * c->hist_len)), dim3(256), 0, c->ctx->stream,
-                       d_if, (const int16_t *)c->d_hist[c->cur], c->d_hist[c->cur ^ 1], (long long)n_samples, (int)c->hist_len,
-                       (int)c->channels);
-    if (int rc = launch_check("history_kernel")) return rc;
+    if (!use_mfb) {            // (the block kernel wrote the next history itself)
+        hipLaunchKernelGGL((history_kernel<int16_t>), dim3(grid_1d((long long)c->channels * c->hist_len)), dim3(256), 0, c->ctx->stream,
+                           d_if, (const int16_t *)c->d_hist[c->cur], c->d_hist[c->cur ^ 1], (long long)n_samples, (int)c->hist_len,
+                           (int)c->channels);
+        if (int rc = launch_check("history_kernel")) return rc;
+    }
     c->cur ^= 1; c->gen++;
     c->phase = (c->phase + (long long)(n_samples % c->osc_len)) % c->osc_len;
     if (c->force_generic) {
@@ -3262,7 +3372,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     }
 
     snprintf(c->info.kernel, sizeof c->info.kernel, "%s%s", kname, c->seq_bq ? " + biquad_df1_seq_kernel" : "");
-    c->info.grid = grid; c->info.block = block; c->info.lds_bytes = (uint32_t)lds;
+    c->info.grid = grid; c->info.block = block; c->info.lds_bytes = (uint32_t)lds_used;
     c->info.time_segments = (uint32_t)nseg; c->info.warmup = (uint32_t)p.warm; c->info.tile = (uint32_t)kTile;
     c->info.taps_padded = c->ntaps_pad;
     c->info.mfma_ksteps = use_mf ? (uint32_t)c->mf_bsteps : use_qm ? (uint32_t)c->qm_bsteps : 0u;

@@ -1,0 +1,254 @@
+"""GPU parity of the fp32 chain at the reference's BLOCK cadence: one AUDIO_BLOCK_SAMPLES = 128 block per call
+(Minimal-SDR.ino:518-530, :574-575), served by chain_mfb_kernel (channel-batched tiles, msdr_chain_mfb.hiph).
+
+Every test streams >= 64 consecutive ticks through the C ABI and compares the whole stream with the oracle's sequential fp32 chain
+(<= 1e-5 relative RMS per channel, the north-star's tolerance); FIR history and cascade state travel from tick to tick through the
+library's ping-pong buffers, written by the block kernel itself."""
+import numpy as np
+import pytest
+
+import orclib
+from gpuhelp import ctx, msdr, rel_rms  # noqa: F401
+from test_gpu_chain import _f32_biquads, _hilbert_pair, _truth_f64, run_chain
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+COS4, SIN4 = np.array([1, 0, -1, 0], np.float32), np.array([0, 1, 0, -1], np.float32)
+
+
+def _lowpass(n_taps, fc=2800.0):
+    k = np.arange(n_taps)
+    h = np.sinc(2 * fc / 24000.0 * (k - (n_taps - 1) / 2.0)) * np.kaiser(n_taps, 7.0)
+    return (h / h.sum()).astype(np.float32)
+
+
+def _if(rng, ch, n):
+    x = rng.integers(-8000, 8001, (ch, n)).astype(np.int16)
+    t = np.arange(n)
+    x[0] = np.round(6000 * (0.5 + 0.4 * np.sin(2 * np.pi * 300 * t / 24000)) * np.cos(2 * np.pi * 6000 * t / 24000)).astype(np.int16)
+    return x
+
+
+def _is_block(chain):
+    return chain.info()["kernel"].startswith("chain_mfb_kernel")
+
+
+@pytest.mark.parametrize("stages", [0, 1, 2])
+@pytest.mark.parametrize("ch", [37, 64])
+def test_block_am_c3_shape_vs_oracle(ctx, orc, stages, ch):
+    """c3 in small: AM channels behind the exact Fs/4 mixer, 256-tap low-pass pair, 0..2 biquad sections; 70 ticks of 128.
+    37 channels: the last tile has idle channel slots."""
+    rng = np.random.default_rng(500 + stages)
+    n = 70 * 128
+    x = _if(rng, ch, n)
+    lp = _lowpass(256)
+    bq = _f32_biquads(orc, stages) if stages else None
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, lp, lp, mixer=msdr.MIXER_FS4, mode=orclib.AM, biquad_coeffs=bq)
+    got = run_chain(ctx, chain, x, np.float32, 128)
+    assert _is_block(chain), chain.info()["kernel"]
+    for c in range(ch):
+        want = orc.chain_f32(x[c], orclib.AM, lp, lp, SIN4, COS4, bq)
+        assert rel_rms(got[c], want) < TOL, (c, rel_rms(got[c], want))
+        assert rel_rms(got[c, -128:], want[-128:]) < TOL, c        # the LAST tick on its own: nothing drifts over the ticks
+
+
+@pytest.mark.parametrize("mode", [orclib.LSB, orclib.USB])
+@pytest.mark.parametrize("stages", [0, 1, 2])
+def test_block_ssb_c4_shape_vs_oracle(ctx, orc, mode, stages):
+    """c4 in small: SSB channels, freq_conv tables at fs/4, 100-tap Hilbert pair (numerator and all-pole response folded into the taps)."""
+    rng = np.random.default_rng(510 + stages)
+    ch, n = 21, 66 * 128
+    x = _if(rng, ch, n)
+    hi, hq = _hilbert_pair(100)
+    k = np.arange(128)       # freq_conv's q15 tables at fs/4, converted as arm_q15_to_float does: exactly period 4 (bench.py workload())
+    oi = (np.round(32767 * np.sin(2 * np.pi * k / 4)).astype(np.int16) / 32768.0).astype(np.float32)
+    oq = (np.round(32767 * np.cos(2 * np.pi * k / 4)).astype(np.int16) / 32768.0).astype(np.float32)
+    bq = _f32_biquads(orc, stages) if stages else None
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, hi, hq, mixer=msdr.MIXER_NCO, mode=mode, osc_i=oi, osc_q=oq, biquad_coeffs=bq)
+    got = run_chain(ctx, chain, x, np.float32, 128)
+    assert _is_block(chain), chain.info()["kernel"]
+    for c in range(ch):
+        want = orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq)
+        err = rel_rms(got[c], want)
+        if err >= TOL:     # a tone on the suppressed sideband: judge both against float64 (tests/test_gpu_chain.py:test_chain_f32_nco_vs_oracle)
+            truth = _truth_f64(x[c], mode, hi, hq, oi, oq, bq)
+            assert rel_rms(got[c], truth) <= max(TOL, 1.5 * rel_rms(want, truth)), (c, err)
+            continue
+        assert err < TOL, (c, err)
+
+
+@pytest.mark.parametrize("block", [32, 64, 256, 512])
+def test_block_other_block_lengths(ctx, orc, block):
+    """Blocks of 32 .. 512 samples take the same kernel (1 .. 16 tile rows per channel)."""
+    rng = np.random.default_rng(520 + block)
+    ch, n = 19, 64 * block
+    x = _if(rng, ch, n)
+    lp, (hi, hq) = _lowpass(128), _hilbert_pair(128)
+    modes = np.array([orclib.AM if c % 3 else orclib.LSB for c in range(ch)], np.int32)
+    tapsets = np.array([0 if m == orclib.AM else 1 for m in modes], np.int32)
+    bq = _f32_biquads(orc, 2)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, [lp, hi], [lp, hq], mixer=msdr.MIXER_FS4, modes=modes, tapsets=tapsets, biquad_coeffs=bq)
+    got = run_chain(ctx, chain, x, np.float32, block)
+    assert _is_block(chain), chain.info()["kernel"]
+    for c in range(ch):
+        want = orc.chain_f32(x[c], modes[c], [lp, hi][tapsets[c]], [lp, hq][tapsets[c]], SIN4, COS4, bq)
+        assert rel_rms(got[c], want) < TOL, (block, c, rel_rms(got[c], want))
+
+
+def test_block_mixed_modes_c5_shape(ctx, orc):
+    """c5 in small at block cadence: per-channel AM / LSB / USB / CW with per-mode 512-tap sets: two launches (SSB tables, envelope tables)."""
+    rng = np.random.default_rng(530)
+    ch, n = 45, 64 * 128
+    x = _if(rng, ch, n)
+    lp, (hi, hq) = _lowpass(512), _hilbert_pair(512)
+    kinds = [orclib.AM, orclib.LSB, orclib.USB, orclib.CW]
+    modes = np.array([kinds[(c * 2654435761 >> 5) & 3] for c in range(ch)], np.int32)
+    tapsets = np.array([0 if m in (orclib.AM, orclib.CW) else 1 for m in modes], np.int32)
+    bq = _f32_biquads(orc, 2)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, [lp, hi], [lp, hq], mixer=msdr.MIXER_FS4, modes=modes, tapsets=tapsets, biquad_coeffs=bq)
+    got = run_chain(ctx, chain, x, np.float32, 128)
+    assert _is_block(chain), chain.info()["kernel"]
+    for c in range(ch):
+        want = orc.chain_f32(x[c], modes[c], [lp, hi][tapsets[c]], [lp, hq][tapsets[c]], SIN4, COS4, bq)
+        assert rel_rms(got[c], want) < TOL, (c, modes[c], rel_rms(got[c], want))
+
+
+def test_block_and_stream_calls_alternate_on_one_chain(ctx, orc):
+    """Call lengths change from call to call: 128-sample ticks (block kernel), long calls (wave-stream kernel), ragged calls (cold
+    tiles) -- history and cascade state are one format, every hand-over is exact to the tolerance."""
+    rng = np.random.default_rng(540)
+    ch = 11
+    plan = [128] * 5 + [4096] + [128] * 3 + [100, 28] + [128] * 4 + [3000, 200] + [64] * 6 + [128] * 40
+    n = sum(plan)
+    x = _if(rng, ch, n)
+    for mode, (ti, tq) in ((orclib.AM, (_lowpass(256),) * 2), (orclib.LSB, _hilbert_pair(100))):
+        bq = _f32_biquads(orc, 2)
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, ti, tq, mixer=msdr.MIXER_FS4, mode=mode, biquad_coeffs=bq)
+        got = np.empty((ch, n), np.float32)
+        o, kernels = 0, set()
+        for m in plan:
+            dx, dy = ctx.to_device(x[:, o:o + m]), ctx.array((ch, m), np.float32)
+            chain.process(dx, dy, m)
+            got[:, o:o + m] = dy.download()
+            kernels.add(chain.info()["kernel"].split("<")[0])
+            o += m
+        assert "chain_mfb_kernel" in kernels and len(kernels) >= 2, kernels
+        for c in range(ch):
+            want = orc.chain_f32(x[c], mode, ti, tq, SIN4, COS4, bq)
+            assert rel_rms(got[c], want) < TOL, (mode, c, rel_rms(got[c], want))
+            o = 0
+            for m in plan:                                           # every call on its own
+                if m >= 64:
+                    assert rel_rms(got[c, o:o + m], want[o:o + m]) < 2 * TOL, (mode, c, o, m)
+                o += m
+
+
+def test_block_kernel_agrees_with_wave_stream_kernel(ctx, orc, monkeypatch):
+    """The same stream through the wave-stream kernel (MSDR_NO_BLOCK=1 at create time) and through the block kernel: the two evaluate
+    the same split-fp16 products in the same order per row; they differ by the cascade's rounding only."""
+    rng = np.random.default_rng(550)
+    ch, n = 24, 64 * 128
+    x = _if(rng, ch, n)
+    lp = _lowpass(256)
+    bq = _f32_biquads(orc, 2)
+    a = msdr.Chain(ctx, msdr.ARITH_F32, ch, lp, lp, mixer=msdr.MIXER_FS4, mode=orclib.AM, biquad_coeffs=bq)
+    monkeypatch.setenv("MSDR_NO_BLOCK", "1")
+    b = msdr.Chain(ctx, msdr.ARITH_F32, ch, lp, lp, mixer=msdr.MIXER_FS4, mode=orclib.AM, biquad_coeffs=bq)
+    monkeypatch.delenv("MSDR_NO_BLOCK")
+    ga, gb = run_chain(ctx, a, x, np.float32, 128), run_chain(ctx, b, x, np.float32, 128)
+    assert _is_block(a) and not _is_block(b), (a.info()["kernel"], b.info()["kernel"])
+    for c in range(ch):
+        assert rel_rms(ga[c], gb[c]) < 2e-6, (c, rel_rms(ga[c], gb[c]))
+
+
+def test_block_int16_audio_out(ctx, orc):
+    """MSDR_CHAIN_OUT_I16 at block cadence: the play queue's sample type written by the block kernel's store phase."""
+    rng = np.random.default_rng(560)
+    ch, n = 16, 64 * 128
+    x = _if(rng, ch, n)
+    lp = _lowpass(102)
+    bq = _f32_biquads(orc, 2)
+    f = msdr.Chain(ctx, msdr.ARITH_F32, ch, lp, lp, mixer=msdr.MIXER_FS4, mode=orclib.AM, biquad_coeffs=bq)
+    q = msdr.Chain(ctx, msdr.ARITH_F32, ch, lp, lp, mixer=msdr.MIXER_FS4, mode=orclib.AM, biquad_coeffs=bq, flags=msdr.CHAIN_OUT_I16)
+    gf, gq = run_chain(ctx, f, x, np.float32, 128), run_chain(ctx, q, x, np.int16, 128)
+    assert _is_block(f) and _is_block(q)
+    want = np.clip(np.trunc((gf * np.float32(32768.0)).astype(np.float64)), -32768, 32767).astype(np.int16)      # arm_float_to_q15
+    assert np.array_equal(gq, want)
+
+
+def test_block_live_updates_between_ticks(ctx, orc):
+    """What the reference changes while the stream runs, between two 128-sample ticks: the bandwidth menu rewrites the AM taps
+    (UI.cpp:332-345), tune() switches a channel's mode, the cascade is re-programmed -- state kept across every change."""
+    rng = np.random.default_rng(570)
+    ch, ticks = 13, 96
+    n = ticks * 128
+    x = _if(rng, ch, n)
+    lp_a, lp_b = _lowpass(102, 2800.0), _lowpass(102, 1500.0)
+    hi, hq = _hilbert_pair(102)
+    bq_a, bq_b = _f32_biquads(orc, 2), _f32_biquads(orc, 2).copy()
+    bq_b[0] = _f32_biquads(orc, 4)[2]                       # another low-pass in section 0
+    modes = np.array([orclib.AM if c % 2 else orclib.LSB for c in range(ch)], np.int32)
+    tapsets = np.array([0 if m == orclib.AM else 1 for m in modes], np.int32)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, [lp_a, hi], [lp_a, hq], mixer=msdr.MIXER_FS4, modes=modes, tapsets=tapsets, biquad_coeffs=bq_a)
+    events = {20: "taps", 40: "mode", 60: "cascade", 80: "taps_back"}
+    got = np.empty((ch, n), np.float32)
+    used = set()
+    for t in range(ticks):
+        ev = events.get(t)
+        if ev == "taps":
+            chain.set_taps(0, lp_b, lp_b)
+        elif ev == "taps_back":
+            chain.set_taps(0, lp_a, lp_a)
+        elif ev == "mode":
+            chain.set_mode(2, orclib.USB, 1)                 # an LSB channel turns USB
+            chain.set_mode(3, orclib.LSB, 1)                 # an AM channel turns LSB (another table part)
+        elif ev == "cascade":
+            chain.set_biquad_coeffs(bq_b)
+        dx, dy = ctx.to_device(x[:, t * 128:(t + 1) * 128]), ctx.array((ch, 128), np.float32)
+        chain.process(dx, dy, 128)
+        got[:, t * 128:(t + 1) * 128] = dy.download()
+        used.add(chain.info()["kernel"].split("<")[0])
+    assert "chain_mfb_kernel" in used, used
+    for c in range(ch):
+        st, want = {}, np.empty(n, np.float32)
+        mode, ts = int(modes[c]), int(tapsets[c])
+        sets_i, sets_q, bq = [lp_a, hi], [lp_a, hq], bq_a
+        bounds = sorted(events) + [ticks]
+        lo = 0
+        for b in bounds:
+            want[lo * 128:b * 128] = orc.chain_f32(x[c, lo * 128:b * 128], mode, sets_i[ts], sets_q[ts], SIN4, COS4, bq, state=st)
+            ev = events.get(b)
+            if ev == "taps":
+                sets_i, sets_q = [lp_b, hi], [lp_b, hq]
+            elif ev == "taps_back":
+                sets_i, sets_q = [lp_a, hi], [lp_a, hq]
+            elif ev == "mode":
+                if c == 2:
+                    mode, ts = orclib.USB, 1
+                if c == 3:
+                    mode, ts = orclib.LSB, 1
+            elif ev == "cascade":
+                bq = bq_b                                      # (CMSIS semantics: the cascade carries on from its pState under the new coefficients)
+            lo = b
+        lo = 0
+        for b in bounds:                                       # every stretch between two changes on its own
+            if True:
+                assert rel_rms(got[c, lo * 128:b * 128], want[lo * 128:b * 128]) < 2 * TOL, (c, lo, rel_rms(got[c, lo * 128:b * 128], want[lo * 128:b * 128]))
+            lo = b
+        assert rel_rms(got[c], want) < 2 * TOL, (c, rel_rms(got[c], want))
+
+
+def test_block_large_batch_many_workgroups(ctx, orc):
+    """4096 channels x 128 (the headline shape at the reference's cadence): 512 tiles, two waves per workgroup; spot-checked channels."""
+    rng = np.random.default_rng(580)
+    ch, ticks = 4096, 8
+    x = rng.integers(-8000, 8001, (ch, ticks * 128)).astype(np.int16)
+    lp = _lowpass(256)
+    bq = _f32_biquads(orc, 2)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, lp, lp, mixer=msdr.MIXER_FS4, mode=orclib.AM, biquad_coeffs=bq)
+    got = run_chain(ctx, chain, x, np.float32, 128)
+    info = chain.info()
+    assert _is_block(chain) and info["grid"] >= 128, info
+    for c in list(range(0, ch, 97)) + [ch - 1]:
+        want = orc.chain_f32(x[c], orclib.AM, lp, lp, SIN4, COS4, bq)
+        assert rel_rms(got[c], want) < TOL, (c, rel_rms(got[c], want))

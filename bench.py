@@ -878,10 +878,23 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
         captured = chain_parity_capture(wl, info, x, y, q15, torch)          # small host copies; the oracle runs after the timed region
         if do_cpu:
             gpu_first = y[:first_rows, :keep].clone()                        # on the device for now
-    chain.enable_timing(True)
-    dt = timed_steps(args, torch, dev, dist, lambda: chain.process(x.data_ptr(), y.data_ptr(), n), after_warmup=chain.kernel_time)
-    kernel_ms, launches = chain.kernel_time()
-    chain.enable_timing(False)
+    if n <= 1024:
+        # block cadence: a tick is ~10 us, and the two HIP events around the main kernel (created and recorded per call) cost a good part of
+        # that on the host -- the K timed steps run WITHOUT them (ms_per_step / value = the tick as a caller sees it), the kernel's own time
+        # comes from K more steps with the events on
+        dt = timed_steps(args, torch, dev, dist, lambda: chain.process(x.data_ptr(), y.data_ptr(), n))
+        chain.enable_timing(True)
+        chain.kernel_time()
+        for _ in range(args.steps):
+            chain.process(x.data_ptr(), y.data_ptr(), n)
+        torch.cuda.synchronize(dev)
+        kernel_ms, launches = chain.kernel_time()
+        chain.enable_timing(False)
+    else:
+        chain.enable_timing(True)
+        dt = timed_steps(args, torch, dev, dist, lambda: chain.process(x.data_ptr(), y.data_ptr(), n), after_warmup=chain.kernel_time)
+        kernel_ms, launches = chain.kernel_time()
+        chain.enable_timing(False)
     power = power_probe(lambda: chain.process(x.data_ptr(), y.data_ptr(), n), torch, dev, dev.index or 0, world) if rank == 0 else None
     if captured is not None:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -1035,6 +1048,9 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
     attach_traffic(out, ("q15_" if q15 else "") + name, args)
     if power:
         out["roofline"].update(power)
+    if n <= 1024:
+        out["roofline"]["tick_us"] = round(dt / args.steps * 1e6, 2)
+        out["roofline"]["note_block"] = "block cadence: ms_per_step / tick_us timed without per-call HIP events; kernel_ms from a second pass with them (events add ~3 us to it)"
     if q15 and len(wl["bq"]):
         # the as-written step = the FIR + demod kernel, then the two Teensy biquad nodes in place on the audio (serial per channel)
         out["roofline"]["step_ms"] = round(dt / args.steps * 1e3, 4)
@@ -1243,13 +1259,25 @@ def main():
                 also["c3_i16"]["warmup_steps_run"] = args.warmup_steps_run
             if also["q15_c3"] is not None:
                 also["q15_c3"]["warmup_steps_run"] = args.warmup_steps_run
+            # the reference's own cadence: ONE 128-sample AudioStream block per call (Minimal-SDR.ino:518-530, :574-575), c3's and c4's channel
+            # counts; `tick_us` = wall time per call with the calls queued back to back.  200 timed steps at least (a tick is ~10-20 us).
+            keep_steps, keep_samples = args.steps, args.samples
+            args.steps, args.samples = max(args.steps, 200), 128
+            for name, wl_name, q in (("c3_b128", "c3", False), ("c4_b128", "c4", False), ("q15_c3_b128", "c3", True)):
+                args.arith = "q15" if q else "f32"
+                also[name] = bench_chain(args, wl_name, torch, msdr, ctx, dev, rank, world, dist, False, False)
+                if also[name] is not None:
+                    also[name]["warmup_steps_run"] = args.warmup_steps_run
+                    also[name]["config"]["steps_timed"] = args.steps
+                    also[name]["roofline"]["tick_us"] = round(also[name]["ms_per_step"] * 1e3, 2)
+            args.arith, args.steps, args.samples = "f32", keep_steps, keep_samples
         args.min_warm_s = 0.0
         if rank == 0:
             for k, rec in also.items():
                 for drop in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "data"):
                     rec.pop(drop, None)
             out["also"] = also
-            out["config"]["records"] = "headline = c3 (BASELINE.json configs[2]); also: fir (256-tap fp32 FIR stage alone), c2, c4, c5, q15_c3 (c3 through the reference's own integer arithmetic, bit-exact) -- each timed over the same K steps; their warm-up is W steps plus 0.2 s of untimed steps (warmup_steps_run), so that short steps are not timed on a card still climbing from its idle clock"
+            out["config"]["records"] = "headline = c3 (BASELINE.json configs[2]); also: fir (256-tap fp32 FIR stage alone), c2, c4, c5, q15_c3 (c3 through the reference's own integer arithmetic, bit-exact), c3_i16, and the 128-sample block cadence c3_b128 / c4_b128 / q15_c3_b128 -- each timed over the same K steps; their warm-up is W steps plus 0.2 s of untimed steps (warmup_steps_run), so that short steps are not timed on a card still climbing from its idle clock"
     if rank == 0:
         import ctypes as C
         ctx.lib.msdr_build_rev.restype = C.c_char_p

@@ -1976,6 +1976,9 @@ struct msdr_chain {
     uint64_t btiles_mode_gen = 0;
     long long btiles_n = -1;
     struct BlockPart { uint32_t wgs = 0, nw = 0, tpw = 0; size_t offset = 0; } bpart[2];
+    // what the per-call kernel choice needs to know about the channels' modes / tap sets / LMS switches, recomputed when they change (a
+    // call at block cadence must not walk 65 536 channels on the host)
+    struct Summary { uint64_t mode_gen = 0, anr_gen = 0; bool any_ssb = false, any_env = false, any_syncam = false, qm_sets_ok = true, any_anr = false; } sum;
     bool block_off = false;              // MSDR_NO_BLOCK=1 at create time: keep the wave-stream kernels at every call length (A/B runs, tests)
     std::vector<std::vector<float>> h_coef_i, h_coef_q;   // host copies for msdr_chain_set_mode
     std::vector<double> h_osc, h_cnum;                    // oscillator pairs {cos, sin}; combined numerator
@@ -2740,6 +2743,26 @@ __global__ void post_hist_copy_kernel(const int16_t *__restrict__ src, int16_t *
     }
 }
 
+static const msdr_chain::Summary &chain_summary(msdr_chain *c)
+{
+    msdr_chain::Summary &u = c->sum;
+    if (u.mode_gen != c->mode_gen) {
+        u.any_ssb = u.any_env = u.any_syncam = false; u.qm_sets_ok = true;
+        for (int m : c->h_mode) {
+            if (m == MSDR_MODE_LSB || m == MSDR_MODE_USB) u.any_ssb = true; else u.any_env = true;
+            if (m == MSDR_MODE_SYNCAM) u.any_syncam = true;
+        }
+        if (!c->qm_set_ok.empty()) for (int ts : c->h_tapset) if (!c->qm_set_ok[ts]) { u.qm_sets_ok = false; break; }
+        u.mode_gen = c->mode_gen;
+    }
+    if (u.anr_gen != c->anr_gen) {
+        u.any_anr = false;
+        for (int v : c->h_anr) if (v > 0) { u.any_anr = true; break; }
+        u.anr_gen = c->anr_gen;
+    }
+    return u;
+}
+
 static bool chain_post_wanted(const msdr_chain *c, uint32_t ch, bool *pll, int *anr)
 {
     *pll = c->f32_pll && c->h_mode[ch] == MSDR_MODE_SYNCAM;
@@ -2843,8 +2866,7 @@ static int chain_post_build(msdr_chain *c)
 // called by msdr_chain_process (F32) after the main kernel: replaces the rows of the post channels in d_audio
 static int chain_post_run(msdr_chain *c, const int16_t *d_if, float *d_audio, uint64_t n)
 {
-    bool any = c->f32_pll;
-    if (!any) for (int v : c->h_anr) if (v > 0) { any = true; break; }
+    const bool any = c->f32_pll || chain_summary(c).any_anr;
     if (!any && !c->aux) return 0;
     if (c->post_mode_gen != c->mode_gen || c->post_anr_gen != c->anr_gen) if (int rc = chain_post_build(c)) return rc;
     if (c->npost == 0) return 0;
@@ -2870,8 +2892,7 @@ static int chain_post_run(msdr_chain *c, const int16_t *d_if, float *d_audio, ui
     hipLaunchKernelGGL(post_pll_f32_kernel, dim3((c->npost + 63) / 64), dim3(64), 0, c->ctx->stream, (const float *)c->d_aux_y, c->d_post_scratch,
                        c->d_post_pll_state, (const int *)c->d_post_ch, (const int *)c->d_post_src, (const int *)c->d_post_pll, c->npost, (long long)n, k);
     if (int rc = launch_check("post_pll_f32_kernel")) return rc;
-    bool any_anr = false;
-    for (int v : c->h_anr) if (v > 0) { any_anr = true; break; }
+    const bool any_anr = chain_summary(c).any_anr;
     if (any_anr) {
         hipLaunchKernelGGL(post_anr_f32_kernel, dim3((c->npost + 63) / 64), dim3(64), 0, c->ctx->stream, c->d_post_scratch, c->d_post_anr_state,
                            (const int *)c->d_post_ch, (const int *)c->d_post_anr, c->npost, (long long)n);
@@ -2919,10 +2940,10 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     // ---- kernel choice: the folded kernel needs a short-period oscillator; AM additionally the exact Fs/4 pattern
     bool use_fold = f32 && c->fold_P > 0;
     if (use_fold && !c->fold_fs4_exact)
-        for (int m : c->h_mode) if (m != MSDR_MODE_LSB && m != MSDR_MODE_USB) { use_fold = false; break; }
+        if (chain_summary(c).any_env) use_fold = false;
     bool pll_active = false;
     if (c->pll) {
-        for (int m : c->h_mode) if (m == MSDR_MODE_SYNCAM) { pll_active = true; break; }
+        pll_active = chain_summary(c).any_syncam;
         if (pll_active) {
             const size_t need = (size_t)c->channels * n_samples;
             if (need > c->pll_q_cap) {
@@ -2958,8 +2979,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     void *fout = d_audio;                                        // where the fp32 passes of this call read and write the audio
     bool i16_via_scratch = false;
     if (f32 && (c->flags & MSDR_CHAIN_OUT_I16)) {
-        bool post_active = c->f32_pll || c->aux != nullptr;
-        for (int v : c->h_anr) if (v > 0) { post_active = true; break; }
+        const bool post_active = c->f32_pll || c->aux != nullptr || chain_summary(c).any_anr;
         if (use_mfw && !c->seq_bq && !post_active) p.dbg |= kChainOutI16;
         else {
             const size_t need = (size_t)c->channels * n_samples;
@@ -2973,7 +2993,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         }
     }
     if (use_qm)
-        for (int ts : c->h_tapset) if (!c->qm_set_ok[ts]) { use_qm = false; break; }      // a tap >= 32640: the VALU kernel runs
+        if (!chain_summary(c).qm_sets_ok) use_qm = false;                                  // a tap >= 32640: the VALU kernel runs
     if (use_mf) use_fold = false;
     const int kTile = use_mfw ? kMwTile : use_fold ? kFoldTile : kChainTile;
     // ---- block cadence (msdr_chain_mfb.hiph): one AUDIO_BLOCK (or another short block) per call -- channel-batched tiles, the next
@@ -2981,9 +3001,9 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     bool use_mfb = false;
     if (use_mfw && !c->block_off && !c->mf_fr && c->nstages <= 2 && mb_n_ok((long long)n_samples) && (int)c->hist_len == c->mf_halo &&
         (reinterpret_cast<uintptr_t>(d_if) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 &&
-        mb_lds_bytes(c->mf_halo, (int)n_samples, c->mf_bsteps, 1) <= 160 * 1024) {
-        bool need_ssb = false, need_env = false;
-        for (int m : c->h_mode) { if (m == MSDR_MODE_LSB || m == MSDR_MODE_USB) need_ssb = true; else need_env = true; }
+        mb_lds_bytes(c->mf_halo, (int)n_samples, c->mf_bsteps, 1, 1) <= 160 * 1024 &&
+        (uint64_t)c->channels * std::max<uint64_t>((uint64_t)c->hist_len * 2, n_samples * 4) < (1ull << 32)) {       // (the kernel addresses with 32-bit byte offsets)
+        const bool need_ssb = chain_summary(c).any_ssb, need_env = chain_summary(c).any_env;
         use_mfb = c->nstages == 0 || ((!need_ssb || c->mfw_ssb_fold) && (!need_env || c->mfw_am_fold));
     }
     p.mf_tab = c->d_mf_tab; p.mf_stride = c->mf_stride; p.mf_halo = c->mf_halo; p.mf_bsteps = c->mf_bsteps; p.bq_mf = c->d_bq_mf; p.bq_mf32 = c->d_bq_mf32;
@@ -3064,20 +3084,32 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
                 bp = msdr_chain::BlockPart();
                 bp.offset = tab.size();
                 if (tiles_part == 0) continue;
-                // waves per workgroup / tiles per wave: the fewest tiles per SIMD (a workgroup's waves spread over the CU's four SIMDs),
-                // ties to fewer waves; one workgroup per CU at these LDS sizes
-                int nwmax = 1;
-                while (nwmax < 8 && mb_lds_bytes(c->mf_halo, n_, c->mf_bsteps, nwmax + 1) <= 160 * 1024) nwmax++;
+                // waves per workgroup / tiles per wave: the least time per workgroup (below), ties to fewer waves; one workgroup per CU at these LDS sizes
+                // (MSDR_MB_NW: experiments / tests; a value that does not fit is ignored -- the loop below must always end with nw, tpw >= 1:
+                //  use_mfb already checked that one wave with one tile fits)
+                int force_nw = 0;
+                if (const char *e = getenv("MSDR_MB_NW")) {
+                    force_nw = std::max(1, std::min(8, atoi(e)));
+                    long long tpw = (tiles_part + (long long)c->ctx->num_cus * force_nw - 1) / ((long long)c->ctx->num_cus * force_nw);
+                    tpw = std::max<long long>(1, std::min<long long>(tpw, kMbMaxTableInts / cpt));
+                    if (mb_lds_bytes(c->mf_halo, n_, c->mf_bsteps, force_nw, (int)tpw) > 160 * 1024) force_nw = 0;
+                }
                 long long best_cost = -1;
-                for (int w = 1; w <= nwmax; w++) {
-                    const long long tpw = (tiles_part + (long long)c->ctx->num_cus * w - 1) / ((long long)c->ctx->num_cus * w);
-                    const long long cost = tpw * ((w + 3) / 4);
+                for (int w = force_nw ? force_nw : 1; w <= (force_nw ? force_nw : 8); w++) {
+                    long long tpw = (tiles_part + (long long)c->ctx->num_cus * w - 1) / ((long long)c->ctx->num_cus * w);
+                    tpw = std::max<long long>(1, std::min<long long>(tpw, kMbMaxTableInts / cpt));           // (a longer list: more workgroups than CUs)
+                    if (mb_lds_bytes(c->mf_halo, n_, c->mf_bsteps, w, (int)tpw) > 160 * 1024) break;
+                    // time of a workgroup ~ tiles per wave x what its fullest SIMD carries: a second wave on a SIMD fills the first one's
+                    // waits (two tiles in ~1.5 x the time of one: profiles/r05/mfb_nw_sweep.txt)
+                    const long long cost = tpw * (w <= 4 ? 2 : 3);
                     if (best_cost < 0 || cost < best_cost) { best_cost = cost; bp.nw = (uint32_t)w; bp.tpw = (uint32_t)tpw; }
                 }
+                if (bp.nw == 0 || bp.tpw == 0) { bp.nw = 1; bp.tpw = 1; }           // (one wave, one tile per wave: checked to fit before this path was taken)
                 const size_t per_wg = (size_t)bp.nw * bp.tpw;
                 for (auto &g : groups) {
                     const size_t tiles_g = ((g.second - g.first) + cpt - 1) / cpt;
                     for (size_t t0 = 0; t0 < tiles_g; t0 += per_wg) {
+                        tab.push_back(fset_of(order[g.first])); tab.push_back(0); tab.push_back(0); tab.push_back(0);      // kMbRecHdrInts
                         const size_t base = tab.size();
                         tab.resize(base + per_wg * cpt, -1);
                         const size_t cnt = std::min(per_wg, tiles_g - t0);
@@ -3177,7 +3209,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             if (bp.wgs == 0) continue;
             ChainParams q = p;
             q.mf_units = c->d_btiles + bp.offset; q.mf_nw = (int)bp.nw; q.nseg = (int)bp.tpw;
-            lds_used = mb_lds_bytes(c->mf_halo, (int)n_samples, c->mf_bsteps, (int)bp.nw);
+            lds_used = mb_lds_bytes(c->mf_halo, (int)n_samples, c->mf_bsteps, (int)bp.nw, (int)bp.tpw);
             if (launch_chain_mfb(c->ctx->stream, (int)c->nstages, part == 1, bp.wgs, bp.nw * 64, lds_used, q) != hipSuccess)
                 return fail(MSDR_STATUS_HIP_ERROR, "chain_mfb_kernel launch failed");
             grid += bp.wgs; block = bp.nw * 64;

@@ -4,15 +4,15 @@ set -u
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 export TMPDIR=/tmp
 O=gpurun_out/r05blk; mkdir -p $O
-timeout -k 10 600 python3 -m pytest tests/test_gpu_block.py -q -m gpu > $O/pytest_block.log 2>&1
+tools/memguard.sh -m 24 -t 600 python3 -m pytest tests/test_gpu_block.py -q -m gpu > $O/pytest_block.log 2>&1
 echo "pytest rc=$?" >> $O/pytest_block.log
 tail -25 $O/pytest_block.log
 export MSDR_BENCH_NO_POWER=1
 for wl in c3 c4; do
-  timeout -k 10 300 python3 bench.py --workload $wl --samples 128 --steps 200 --warmup 20 --no-cpu > $O/${wl}_b128.json 2> $O/${wl}_b128.err
+  tools/memguard.sh -m 24 -t 300 python3 bench.py --workload $wl --samples 128 --steps 200 --warmup 20 --no-cpu > $O/${wl}_b128.json 2> $O/${wl}_b128.err
 done
-timeout -k 10 300 python3 bench.py --workload c4 --samples 128 --channels 65536 --steps 200 --warmup 20 --no-cpu > $O/c4_b128_64k.json 2> $O/c4_b128_64k.err
-timeout -k 10 300 python3 bench.py --workload c3 --samples 128 --channels 65536 --steps 200 --warmup 20 --no-cpu > $O/c3_b128_64k.json 2> $O/c3_b128_64k.err
+tools/memguard.sh -m 24 -t 300 python3 bench.py --workload c4 --samples 128 --channels 65536 --steps 200 --warmup 20 --no-cpu > $O/c4_b128_64k.json 2> $O/c4_b128_64k.err
+tools/memguard.sh -m 24 -t 300 python3 bench.py --workload c3 --samples 128 --channels 65536 --steps 200 --warmup 20 --no-cpu > $O/c3_b128_64k.json 2> $O/c3_b128_64k.err
 for f in $O/*.json; do python3 - "$f" <<'PY'
 import json,sys
 try:

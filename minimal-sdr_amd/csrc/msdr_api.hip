@@ -17,6 +17,7 @@
 #include "msdr_fir_f32tq.hiph"
 #include "msdr_chain_amtr.hiph"
 #include "msdr_chain_mfb.hiph"
+#include "msdr_chain_q15mb.hiph"
 #include "msdr_block.h"
 #include "msdr_design.h"
 #include "msdr_cascade_state.h"
@@ -2123,6 +2124,8 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
     c->hist_len = c->ntaps_pad - 1; c->tapsets = cfg->num_tapsets;
     if (f32 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && mf_halo((int)(cfg->num_taps + 2 * cfg->num_biquad_stages)) <= 2048)      // the matrix-core kernel's window halo
         c->hist_len = std::max<uint32_t>(c->hist_len, (uint32_t)mf_halo((int)(cfg->num_taps + 2 * cfg->num_biquad_stages)));
+    if (!f32 && !(cfg->flags & MSDR_CHAIN_NO_MFMA) && qm_halo((int)cfg->num_taps) <= 512)                   // the integer matrix-core kernels' window halo:
+        c->hist_len = std::max<uint32_t>(c->hist_len, (uint32_t)qm_halo((int)cfg->num_taps));                  // whole 16-byte groups per history row (block cadence)
     c->osc_len = (cfg->mixer == MSDR_MIXER_NCO) ? cfg->osc_len : 4;
     c->in_scale = (cfg->in_scale == 0.0f) ? 1.0f / 32768.0f : cfg->in_scale;
     c->nstages = f32 ? cfg->num_biquad_stages : 0;
@@ -2916,6 +2919,88 @@ __global__ void f32_to_q15_kernel(const float *__restrict__ src, short *__restri
     }
 }
 
+// ---- block cadence (msdr_chain_mfb.hiph, msdr_chain_q15mb.hiph): the tile table ------------------------------------------------------------------
+// CPT channels per tile, channels grouped by `key_of` (the table set / tap set a workgroup's waves share) inside two parts (`part_of`: SSB
+// tables first, envelope tables after: two launches of two kernels); a workgroup's record = {key, 0, 0, 0} | nw waves x tpw tiles of ONE key, a
+// group's tiles dealt round-robin to the waves, idle slots = -1.  Cached per (modes, n).
+static int chain_block_tiles(msdr_chain *c, int n_, const std::function<int(uint32_t)> &part_of, const std::function<int(uint32_t)> &key_of,
+                             const std::function<size_t(int, int)> &lds_of)
+{
+    if (c->btiles_mode_gen == c->mode_gen && c->btiles_n == (long long)n_) return 0;
+    const int cpt = mb_cpt(n_);
+    std::vector<uint32_t> order(c->channels);
+    for (uint32_t i = 0; i < c->channels; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return part_of(a) * 1000000 + key_of(a) < part_of(b) * 1000000 + key_of(b); });
+    std::vector<int> tab;
+    size_t i0 = 0;
+    for (int part = 0; part < 2; part++) {
+        std::vector<std::pair<size_t, size_t>> groups;          // [begin, end) in `order`
+        size_t i = i0;
+        long long tiles_part = 0;
+        while (i < order.size() && part_of(order[i]) == part) {
+            size_t j = i;
+            while (j < order.size() && part_of(order[j]) == part && key_of(order[j]) == key_of(order[i])) j++;
+            groups.emplace_back(i, j);
+            tiles_part += (long long)((j - i) + cpt - 1) / cpt;
+            i = j;
+        }
+        i0 = i;
+        msdr_chain::BlockPart &bp = c->bpart[part];
+        bp = msdr_chain::BlockPart();
+        bp.offset = tab.size();
+        if (tiles_part == 0) continue;
+        // waves per workgroup / tiles per wave: the least time per workgroup (below), ties to fewer waves; one workgroup per CU at these LDS sizes
+        // (MSDR_MB_NW: experiments / tests; a value that does not fit is ignored -- the loop below must always end with nw, tpw >= 1:
+        //  the caller checked that one wave with one tile fits)
+        int force_nw = 0;
+        if (const char *e = getenv("MSDR_MB_NW")) {
+            force_nw = std::max(1, std::min(8, atoi(e)));
+            long long tpw = (tiles_part + (long long)c->ctx->num_cus * force_nw - 1) / ((long long)c->ctx->num_cus * force_nw);
+            tpw = std::max<long long>(1, std::min<long long>(tpw, kMbMaxTableInts / cpt));
+            if (lds_of(force_nw, (int)tpw) > 160 * 1024) force_nw = 0;
+        }
+        long long best_cost = -1;
+        for (int w = force_nw ? force_nw : 1; w <= (force_nw ? force_nw : 8); w++) {
+            long long tpw = (tiles_part + (long long)c->ctx->num_cus * w - 1) / ((long long)c->ctx->num_cus * w);
+            tpw = std::max<long long>(1, std::min<long long>(tpw, kMbMaxTableInts / cpt));           // (a longer list: more workgroups than CUs)
+            if (lds_of(w, (int)tpw) > 160 * 1024) break;
+            // time of a workgroup ~ tiles per wave x what its fullest SIMD carries: a second wave on a SIMD fills the first one's
+            // waits (two tiles in ~1.5 x the time of one: profiles/r05/mfb_nw_sweep.txt)
+            const long long cost = tpw * (w <= 4 ? 2 : 3);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; bp.nw = (uint32_t)w; bp.tpw = (uint32_t)tpw; }
+        }
+        if (bp.nw == 0 || bp.tpw == 0) { bp.nw = 1; bp.tpw = 1; }
+        const size_t per_wg = (size_t)bp.nw * bp.tpw;
+        for (auto &g : groups) {
+            const size_t tiles_g = ((g.second - g.first) + cpt - 1) / cpt;
+            for (size_t t0 = 0; t0 < tiles_g; t0 += per_wg) {
+                tab.push_back(key_of(order[g.first])); tab.push_back(0); tab.push_back(0); tab.push_back(0);      // kMbRecHdrInts
+                const size_t base = tab.size();
+                tab.resize(base + per_wg * cpt, -1);
+                const size_t cnt = std::min(per_wg, tiles_g - t0);
+                for (size_t t = 0; t < cnt; t++) {           // tile t of this workgroup -> wave t % nw, its slot t / nw
+                    const size_t slot = (t % bp.nw) * bp.tpw + t / bp.nw;
+                    for (int k = 0; k < cpt; k++) {
+                        const size_t idx = g.first + (t0 + t) * cpt + k;
+                        if (idx < g.second) tab[base + slot * cpt + k] = (int)order[idx];
+                    }
+                }
+                bp.wgs++;
+            }
+        }
+    }
+    if (tab.size() > c->btiles_cap) {
+        HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+        hipFree(c->d_btiles); c->d_btiles = nullptr; c->btiles_cap = 0;
+        if (int rc = dzalloc(c->ctx, tab.size(), &c->d_btiles)) return rc;
+        c->btiles_cap = tab.size();
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_btiles, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));        // `tab` is a local
+    c->btiles_mode_gen = c->mode_gen; c->btiles_n = (long long)n_;
+    return 0;
+}
+
 static int chain_leave_generic(msdr_chain *c);
 extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_audio, uint64_t n_samples)
 {
@@ -3007,6 +3092,12 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         use_mfb = c->nstages == 0 || ((!need_ssb || c->mfw_ssb_fold) && (!need_env || c->mfw_am_fold));
     }
     p.mf_tab = c->d_mf_tab; p.mf_stride = c->mf_stride; p.mf_halo = c->mf_halo; p.mf_bsteps = c->mf_bsteps; p.bq_mf = c->d_bq_mf; p.bq_mf32 = c->d_bq_mf32;
+    // the same for the Q15 chain (msdr_chain_q15mb.hiph); SYNCAM channels under the PLL hand I and Q to a kernel behind: the streaming kernel
+    bool use_qb = false;
+    if (use_qm && chain_summary(c).qm_sets_ok && !c->block_off && !c->qm_fr && !pll_active && mb_n_ok((long long)n_samples) && (int)c->hist_len == c->qm_halo &&
+        (reinterpret_cast<uintptr_t>(d_if) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 &&
+        qb_lds_bytes(c->qm_halo, (int)n_samples, c->qm_bsteps, 1, 1) <= 160 * 1024 &&
+        (uint64_t)c->channels * std::max<uint64_t>((uint64_t)c->hist_len * 2, n_samples * 2) < (1ull << 32)) use_qb = true;
     const int osc_P = use_mf ? c->mf_P : c->fold_P;            // the matrix-core tables exist for periods up to 32, the VALU fold tables up to 4
     p.ftaps = c->d_ftaps; p.chan_fset = c->d_fset; p.fold_period = osc_P; p.bq_fold = c->d_bq_fold;
     p.fold_rot = osc_P ? (int)(c->phase % osc_P) : 0;
@@ -3056,86 +3147,16 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
 
     unsigned grid = (unsigned)(c->channels * nseg);
     if (use_mfb) {
-        // tile table: CPT channels per tile, channels grouped by table set (SSB tables first, envelope tables after: two launches of two
-        // kernels); a workgroup = nw waves x tpw tiles of ONE table set, a group's tiles dealt round-robin to the waves, idle slots = -1
-        const int n_ = (int)n_samples, cpt = mb_cpt(n_);
-        if (c->btiles_mode_gen != c->mode_gen || c->btiles_n != (long long)n_samples) {
-            std::vector<uint32_t> order(c->channels);
-            for (uint32_t i = 0; i < c->channels; i++) order[i] = i;
-            auto fset_of = [&](uint32_t ch) { const int m = c->h_mode[ch]; return c->h_tapset[ch] * 3 + (m == MSDR_MODE_LSB ? 0 : m == MSDR_MODE_USB ? 1 : 2); };
-            auto env_of = [&](uint32_t ch) { return fset_of(ch) % 3 == 2 ? 1 : 0; };
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return env_of(a) * 1000000 + fset_of(a) < env_of(b) * 1000000 + fset_of(b); });
-            std::vector<int> tab;
-            size_t i0 = 0;
-            for (int part = 0; part < 2; part++) {
-                // the part's groups and tile count
-                std::vector<std::pair<size_t, size_t>> groups;          // [begin, end) in `order`
-                size_t i = i0;
-                long long tiles_part = 0;
-                while (i < order.size() && env_of(order[i]) == part) {
-                    size_t j = i;
-                    while (j < order.size() && fset_of(order[j]) == fset_of(order[i])) j++;
-                    groups.emplace_back(i, j);
-                    tiles_part += (long long)((j - i) + cpt - 1) / cpt;
-                    i = j;
-                }
-                i0 = i;
-                msdr_chain::BlockPart &bp = c->bpart[part];
-                bp = msdr_chain::BlockPart();
-                bp.offset = tab.size();
-                if (tiles_part == 0) continue;
-                // waves per workgroup / tiles per wave: the least time per workgroup (below), ties to fewer waves; one workgroup per CU at these LDS sizes
-                // (MSDR_MB_NW: experiments / tests; a value that does not fit is ignored -- the loop below must always end with nw, tpw >= 1:
-                //  use_mfb already checked that one wave with one tile fits)
-                int force_nw = 0;
-                if (const char *e = getenv("MSDR_MB_NW")) {
-                    force_nw = std::max(1, std::min(8, atoi(e)));
-                    long long tpw = (tiles_part + (long long)c->ctx->num_cus * force_nw - 1) / ((long long)c->ctx->num_cus * force_nw);
-                    tpw = std::max<long long>(1, std::min<long long>(tpw, kMbMaxTableInts / cpt));
-                    if (mb_lds_bytes(c->mf_halo, n_, c->mf_bsteps, force_nw, (int)tpw) > 160 * 1024) force_nw = 0;
-                }
-                long long best_cost = -1;
-                for (int w = force_nw ? force_nw : 1; w <= (force_nw ? force_nw : 8); w++) {
-                    long long tpw = (tiles_part + (long long)c->ctx->num_cus * w - 1) / ((long long)c->ctx->num_cus * w);
-                    tpw = std::max<long long>(1, std::min<long long>(tpw, kMbMaxTableInts / cpt));           // (a longer list: more workgroups than CUs)
-                    if (mb_lds_bytes(c->mf_halo, n_, c->mf_bsteps, w, (int)tpw) > 160 * 1024) break;
-                    // time of a workgroup ~ tiles per wave x what its fullest SIMD carries: a second wave on a SIMD fills the first one's
-                    // waits (two tiles in ~1.5 x the time of one: profiles/r05/mfb_nw_sweep.txt)
-                    const long long cost = tpw * (w <= 4 ? 2 : 3);
-                    if (best_cost < 0 || cost < best_cost) { best_cost = cost; bp.nw = (uint32_t)w; bp.tpw = (uint32_t)tpw; }
-                }
-                if (bp.nw == 0 || bp.tpw == 0) { bp.nw = 1; bp.tpw = 1; }           // (one wave, one tile per wave: checked to fit before this path was taken)
-                const size_t per_wg = (size_t)bp.nw * bp.tpw;
-                for (auto &g : groups) {
-                    const size_t tiles_g = ((g.second - g.first) + cpt - 1) / cpt;
-                    for (size_t t0 = 0; t0 < tiles_g; t0 += per_wg) {
-                        tab.push_back(fset_of(order[g.first])); tab.push_back(0); tab.push_back(0); tab.push_back(0);      // kMbRecHdrInts
-                        const size_t base = tab.size();
-                        tab.resize(base + per_wg * cpt, -1);
-                        const size_t cnt = std::min(per_wg, tiles_g - t0);
-                        for (size_t t = 0; t < cnt; t++) {           // tile t of this workgroup -> wave t % nw, its slot t / nw
-                            const size_t slot = (t % bp.nw) * bp.tpw + t / bp.nw;
-                            for (int k = 0; k < cpt; k++) {
-                                const size_t idx = g.first + (t0 + t) * cpt + k;
-                                if (idx < g.second) tab[base + slot * cpt + k] = (int)order[idx];
-                            }
-                        }
-                        bp.wgs++;
-                    }
-                }
-            }
-            if (tab.size() > c->btiles_cap) {
-                HIP_TRY(hipStreamSynchronize(c->ctx->stream));
-                hipFree(c->d_btiles); c->d_btiles = nullptr; c->btiles_cap = 0;
-                if (int rc = dzalloc(c->ctx, tab.size(), &c->d_btiles)) return rc;
-                c->btiles_cap = tab.size();
-            }
-            HIP_TRY(hipMemcpyAsync(c->d_btiles, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, c->ctx->stream));
-            HIP_TRY(hipStreamSynchronize(c->ctx->stream));        // `tab` is a local
-            c->btiles_mode_gen = c->mode_gen; c->btiles_n = (long long)n_samples;
-        }
+        auto fset_of = [&](uint32_t ch) { const int m = c->h_mode[ch]; return c->h_tapset[ch] * 3 + (m == MSDR_MODE_LSB ? 0 : m == MSDR_MODE_USB ? 1 : 2); };
+        if (int rc = chain_block_tiles(c, (int)n_samples, [&](uint32_t ch) { return fset_of(ch) % 3 == 2 ? 1 : 0; }, fset_of,
+                                       [&](int w, int tpw) { return mb_lds_bytes(c->mf_halo, (int)n_samples, c->mf_bsteps, w, tpw); })) return rc;
         nseg = 1; p.nseg = 1; p.warm = 0;
         p.bq_state_out = c->d_bq_state_alt; p.mw_iir = c->d_mw_iir;
+    } else if (use_qb) {
+        if (int rc = chain_block_tiles(c, (int)n_samples, [&](uint32_t ch) { const int m = c->h_mode[ch]; return (m == MSDR_MODE_LSB || m == MSDR_MODE_USB) ? 0 : 1; },
+                                       [&](uint32_t ch) { return c->h_tapset[ch]; },
+                                       [&](int w, int tpw) { return qb_lds_bytes(c->qm_halo, (int)n_samples, c->qm_bsteps, w, tpw); })) return rc;
+        nseg = 1; p.nseg = 1; p.warm = 0;
     } else
     if (use_mfw) {
         // unit table: (channel, segment) per wave; the waves of a workgroup share one tap table, so channels are grouped by
@@ -3287,6 +3308,22 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     else if (use_fold && c->fold_P == 2) { hipLaunchKernelGGL((chain_fold_kernel<2>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<2>"; }
     else if (use_fold) { hipLaunchKernelGGL((chain_fold_kernel<1>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<1>"; }
     else if (f32) hipLaunchKernelGGL((chain_kernel<ArithF32>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p);
+    else if (use_qb) {
+        grid = 0;
+        for (int part = 0; part < 2; part++) {
+            const msdr_chain::BlockPart &bp = c->bpart[part];
+            if (bp.wgs == 0) continue;
+            ChainParams q = p;
+            q.mf_tab = c->d_qm_tab; q.mf_stride = c->qm_stride; q.mf_halo = c->qm_halo; q.mf_bsteps = c->qm_bsteps;
+            q.mf_units = c->d_btiles + bp.offset; q.mf_nw = (int)bp.nw; q.nseg = (int)bp.tpw;
+            lds_used = qb_lds_bytes(c->qm_halo, (int)n_samples, c->qm_bsteps, (int)bp.nw, (int)bp.tpw);
+            const int flavour = part == 0 ? 0 : (c->sqrt_kind == 1 ? 2 : 1);
+            if (launch_chain_q15mb(c->ctx->stream, flavour, bp.wgs, bp.nw * 64, lds_used, q) != hipSuccess)
+                return fail(MSDR_STATUS_HIP_ERROR, "chain_q15mb_kernel launch failed");
+            grid += bp.wgs; block = bp.nw * 64;
+        }
+        kname = "chain_q15mb_kernel (channel-batched block tiles)";
+    }
     else if (use_qm) {
         // channels grouped by (tap set, flavour): a workgroup's waves share one table; one launch per group in use
         const int env_flavour = (c->sqrt_kind == 1) ? 2 : 1;
@@ -3389,7 +3426,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         if (int rc = launch_check("f32_to_q15_kernel")) return rc;
     }
 
-    if (!use_mfb) {            // (the block kernel wrote the next history itself)
+    if (!use_mfb && !use_qb) {            // (the block kernels write the next history themselves)
         hipLaunchKernelGGL((history_kernel<int16_t>), dim3(grid_1d((long long)c->channels * c->hist_len)), dim3(256), 0, c->ctx->stream,
                            d_if, (const int16_t *)c->d_hist[c->cur], c->d_hist[c->cur ^ 1], (long long)n_samples, (int)c->hist_len,
                            (int)c->channels);

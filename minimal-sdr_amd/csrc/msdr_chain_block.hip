@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <vector>
 #include "msdr_chain_mfb.hiph"
+#include "msdr_chain_q15mb.hiph"
 #include "msdr_block.h"
 
 namespace msdr {
@@ -37,6 +38,17 @@ hipError_t launch_chain_mfb(hipStream_t stream, int stages, bool am, unsigned gr
                          cnt, p.nseg, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt);
     }
 #endif
+    return hipGetLastError();
+}
+
+hipError_t launch_chain_q15mb(hipStream_t stream, int flavour, unsigned grid, unsigned block, size_t lds, const ChainParams &p)
+{
+    switch (flavour) {
+    case 0: hipLaunchKernelGGL((chain_q15mb_kernel<0>), dim3(grid), dim3(block), lds, stream, p); break;
+    case 1: hipLaunchKernelGGL((chain_q15mb_kernel<1>), dim3(grid), dim3(block), lds, stream, p); break;
+    case 2: hipLaunchKernelGGL((chain_q15mb_kernel<2>), dim3(grid), dim3(block), lds, stream, p); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -252,3 +252,149 @@ def test_block_large_batch_many_workgroups(ctx, orc):
     for c in list(range(0, ch, 97)) + [ch - 1]:
         want = orc.chain_f32(x[c], orclib.AM, lp, lp, SIN4, COS4, bq)
         assert rel_rms(got[c], want) < TOL, (c, rel_rms(got[c], want))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# the reference AS WRITTEN at its own cadence: chain_q15mb_kernel (msdr_chain_q15mb.hiph) + the Teensy biquad nodes, bit-exact
+# ------------------------------------------------------------------------------------------------------------------------------------
+from test_gpu_chain import _ref_nodes  # noqa: E402
+
+
+def _is_qblock(chain):
+    return chain.info()["kernel"].startswith("chain_q15mb_kernel")
+
+
+@pytest.mark.parametrize("mixer", [0, 1])
+@pytest.mark.parametrize("sqrt_kind", [0, 1])
+def test_block_q15_reference_graph_64_ticks_bit_exact(ctx, orc, golden, mixer, sqrt_kind):
+    """demodulation() + biquad1_dac + biquad2_dac, one 128-sample block per call for 64 calls, per-channel mode and tap set (the
+    reference's own tap tables), retunes between ticks: every sample equal to the oracle's (FIR part pinned to the compiled reference)."""
+    rng = np.random.default_rng(600 + 2 * mixer + sqrt_kind)
+    ch, ticks = 70, 64
+    pad = lambda t: np.concatenate([np.zeros(102 - t.size, np.int16), t])
+    sets_i = [golden["fir/taps_am102"], pad(golden["taps/FIR_SSB_I_coeffs"]), pad(golden["taps/FIR_CW_I_coeffs"])]
+    sets_q = [golden["fir/taps_am102"], pad(golden["taps/FIR_SSB_Q_coeffs"]), pad(golden["taps/FIR_CW_Q_coeffs"])]
+    lp, nt = _ref_nodes(orc)
+    oi = oq = None
+    if mixer:
+        k = np.arange(128)
+        oi = np.round(32767 * np.sin(2 * np.pi * k / 4)).astype(np.int16)
+        oq = np.round(32767 * np.cos(2 * np.pi * k / 4)).astype(np.int16)
+    modes = rng.integers(1, 5, ch).astype(np.int32)
+    tapsets = rng.integers(0, 3, ch).astype(np.int32)
+    x = rng.integers(-32768, 32768, (ch, ticks * 128)).astype(np.int16)
+    x[3] = -32768                                               # the mixer's wrapping negate, the envelope's wrapping sum
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, sets_i, sets_q, mixer=mixer, modes=modes, tapsets=tapsets, osc_i=oi, osc_q=oq,
+                       sqrt_kind=sqrt_kind, biquad_nodes=[[lp], [nt]])
+    watch = [0, 1, 3, 17, 63, 64, 69]
+    states = {c: {} for c in watch}
+    got = np.empty((ch, ticks * 128), np.int16)
+    marks = {c: [0] for c in watch}                            # tick indices where channel c's mode / tap set changed
+    hist = {c: [(int(modes[c]), int(tapsets[c]))] for c in watch}
+    for t in range(ticks):
+        if t in (16, 33, 50):
+            for c in watch[(t % 2)::2] + [5, 40]:
+                modes[c], tapsets[c] = int(rng.integers(1, 5)), int(rng.integers(0, 3))
+                chain.set_mode(c, int(modes[c]), int(tapsets[c]))
+                if c in marks:
+                    marks[c].append(t); hist[c].append((int(modes[c]), int(tapsets[c])))
+        dx, dy = ctx.to_device(x[:, t * 128:(t + 1) * 128]), ctx.array((ch, 128), np.int16)
+        chain.process(dx, dy, 128)
+        got[:, t * 128:(t + 1) * 128] = dy.download()
+        assert _is_qblock(chain), chain.info()["kernel"]
+    for c in watch:
+        bounds = marks[c] + [ticks]
+        for (lo, hi), (m, ts) in zip(zip(bounds[:-1], bounds[1:]), hist[c]):
+            want = orc.chain_q15(x[c, lo * 128:hi * 128], m, sets_i[ts], sets_q[ts], mixer=mixer, osc_i=oi, osc_q=oq, sqrt_kind=sqrt_kind,
+                                 biquads=[orc.biquad_teensy_new([lp]), orc.biquad_teensy_new([nt])], state=states[c])
+            assert np.array_equal(got[c, lo * 128:hi * 128], want), (c, lo, hi, m, ts)
+
+
+def test_block_q15_matches_reference_golden_and_stream_kernel(ctx, golden, monkeypatch):
+    """The reference-generated golden chain vectors at block cadence, and the same through the streaming kernel (MSDR_NO_BLOCK=1)."""
+    sigs = ["am", "tones", "noise", "full"]
+    x = np.stack([golden["chain/x_" + s] for s in sigs])
+    for mn, mode, ti, tq in (("AM", orclib.AM, "fir/taps_am102", "fir/taps_am102"), ("LSB", orclib.LSB, "taps/FIR_SSB_I_coeffs", "taps/FIR_SSB_Q_coeffs"),
+                             ("USB", orclib.USB, "taps/FIR_SSB_I_coeffs", "taps/FIR_SSB_Q_coeffs"), ("CW", orclib.CW, "taps/FIR_CW_I_coeffs", "taps/FIR_CW_Q_coeffs")):
+        a = msdr.Chain(ctx, msdr.ARITH_Q15, len(sigs), golden[ti], golden[tq], mode=mode)
+        monkeypatch.setenv("MSDR_NO_BLOCK", "1")
+        b = msdr.Chain(ctx, msdr.ARITH_Q15, len(sigs), golden[ti], golden[tq], mode=mode)
+        monkeypatch.delenv("MSDR_NO_BLOCK")
+        ga, gb = run_chain(ctx, a, x, np.int16, 128), run_chain(ctx, b, x, np.int16, 128)
+        assert _is_qblock(a) and not _is_qblock(b), (a.info()["kernel"], b.info()["kernel"])
+        for c, s in enumerate(sigs):
+            assert np.array_equal(ga[c], golden["chain/%s_%s_audio" % (s, mn)]), (s, mn)
+        assert np.array_equal(ga, gb)
+
+
+@pytest.mark.parametrize("block", [32, 64, 256, 512])
+def test_block_q15_other_block_lengths_and_long_taps(ctx, orc, block):
+    """256-tap designer low-pass (c3's filter as the reference designs it) and a 256-tap pair, blocks of 32 .. 512, calls of other
+    lengths in between (the streaming kernel takes those: one history format)."""
+    rng = np.random.default_rng(620 + block)
+    ch = 19
+    am = orc.calc_fir_coeffs(256, 2800.0)[:256].copy()
+    hi = np.round(_hilbert_pair(256)[0].astype(np.float64) * 32767).astype(np.int16)
+    hq = np.round(_hilbert_pair(256)[1].astype(np.float64) * 32767).astype(np.int16)
+    modes = np.array([orclib.AM if c % 3 else orclib.USB for c in range(ch)], np.int32)
+    tapsets = np.array([0 if m == orclib.AM else 1 for m in modes], np.int32)
+    plan = [block] * 20 + [1024 + 128] + [block] * 20 + [128 * 3] + [block] * 24
+    plan = [m for m in plan if m % 128 == 0 or m == block]
+    n = sum(plan)
+    pad = (-n) % 128
+    if pad:
+        plan.append(pad); n += pad
+    x = rng.integers(-20000, 20001, (ch, n)).astype(np.int16)
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, [am, hi], [am, hq], modes=modes, tapsets=tapsets)
+    got = np.empty((ch, n), np.int16)
+    o, kernels = 0, set()
+    for m in plan:
+        dx, dy = ctx.to_device(x[:, o:o + m]), ctx.array((ch, m), np.int16)
+        chain.process(dx, dy, m)
+        got[:, o:o + m] = dy.download()
+        kernels.add(chain.info()["kernel"].split(" ")[0].split("<")[0])
+        o += m
+    assert "chain_q15mb_kernel" in kernels, kernels
+    for c in range(ch):
+        want = orc.chain_q15(x[c], int(modes[c]), [am, hi][tapsets[c]], [am, hq][tapsets[c]])
+        assert np.array_equal(got[c], want), (block, c)
+
+
+def test_block_q15_live_tap_and_node_updates(ctx, orc):
+    """The bandwidth menu rewrites FIR_AM_coeffs in place (UI.cpp:332-345) and tune() re-programs biquad2_dac (Minimal-SDR.ino:356) between
+    two 128-sample ticks: FIR state and node history kept, bit-exact."""
+    import ctypes as C
+    rng = np.random.default_rng(640)
+    ch, ticks = 33, 72
+    lp, nt = _ref_nodes(orc)
+    nt2 = orc.biquad_design(orclib.BQ_NOTCH, np.float32(2950.0 * orclib.AUDIO_SAMPLE_RATE_EXACT / 24000.0), 15.0)
+    taps = [orc.calc_fir_coeffs(102, float(bw))[:102].copy() for bw in (2800, 1500, 4000)]
+    x = rng.integers(-20000, 20001, (ch, ticks * 128)).astype(np.int16)
+    chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, taps[0], taps[0], mode=orclib.AM, biquad_nodes=[[lp], [nt]])
+    cur = taps[0]
+    states = {c: {} for c in range(0, ch, 4)}
+    nodes = {c: [orc.biquad_teensy_new([lp]), orc.biquad_teensy_new([nt])] for c in states}
+    lo = 0
+    got = np.empty((ch, ticks * 128), np.int16)
+    events = {18: ("taps", taps[1]), 36: ("node", nt2), 54: ("taps", taps[2])}
+    for t in range(ticks + 1):
+        ev = events.get(t)
+        if ev or t == ticks:
+            for c in states:                                   # the stretch up to this change
+                want = orc.chain_q15(x[c, lo * 128:t * 128], orclib.AM, cur, cur, biquads=nodes[c], state=states[c])
+                assert np.array_equal(got[c, lo * 128:t * 128], want), (c, lo, t)
+            lo = t
+            if t == ticks:
+                break
+            if ev[0] == "taps":
+                chain.set_taps(0, ev[1], ev[1]); cur = ev[1]
+            else:
+                chain.set_node_coefficients(1, 0, ev[1])
+                for c in states:
+                    recs = states[c].get("bq", nodes[c])
+                    orc.lib.orc_biquad_teensy_set_coefficients(C.byref(recs[1]), C.c_uint32(0), orclib._ptr(np.ascontiguousarray(ev[1], np.int32)))
+                    states[c]["bq"] = recs
+        dx, dy = ctx.to_device(x[:, t * 128:(t + 1) * 128]), ctx.array((ch, 128), np.int16)
+        chain.process(dx, dy, 128)
+        got[:, t * 128:(t + 1) * 128] = dy.download()
+        assert _is_qblock(chain), chain.info()["kernel"]

@@ -883,13 +883,15 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
         # that on the host -- the K timed steps run WITHOUT them (ms_per_step / value = the tick as a caller sees it), the kernel's own time
         # comes from K more steps with the events on
         dt = timed_steps(args, torch, dev, dist, lambda: chain.process(x.data_ptr(), y.data_ptr(), n))
-        chain.enable_timing(True)
-        chain.kernel_time()
+        # device time per tick: ONE event pair around K more back-to-back calls on the launch stream (kernel + the dispatch gap to the next
+        # one; per-call event pairs cost ~3 us each at this size and would time themselves); rocprofv3's per-kernel average: profiles/r05
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         for _ in range(args.steps):
             chain.process(x.data_ptr(), y.data_ptr(), n)
+        e1.record()
         torch.cuda.synchronize(dev)
-        kernel_ms, launches = chain.kernel_time()
-        chain.enable_timing(False)
+        kernel_ms, launches = e0.elapsed_time(e1), args.steps
     else:
         chain.enable_timing(True)
         dt = timed_steps(args, torch, dev, dist, lambda: chain.process(x.data_ptr(), y.data_ptr(), n), after_warmup=chain.kernel_time)
@@ -1050,7 +1052,7 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
         out["roofline"].update(power)
     if n <= 1024:
         out["roofline"]["tick_us"] = round(dt / args.steps * 1e6, 2)
-        out["roofline"]["note_block"] = "block cadence: ms_per_step / tick_us timed without per-call HIP events; kernel_ms from a second pass with them (events add ~3 us to it)"
+        out["roofline"]["note_block"] = "block cadence: kernel_ms = device time per call from one HIP event pair around K back-to-back calls (kernels + dispatch gaps)"
     if q15 and len(wl["bq"]):
         # the as-written step = the FIR + demod kernel, then the two Teensy biquad nodes in place on the audio (serial per channel)
         out["roofline"]["step_ms"] = round(dt / args.steps * 1e3, 4)

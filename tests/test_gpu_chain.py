@@ -601,8 +601,10 @@ QM, VALU = "chain_q15mf_kernel", "chain_kernel<ArithQ15>"
 
 @pytest.mark.parametrize("mn,mode,ti,tq", CHAIN)
 @pytest.mark.parametrize("flags,kernel", [(0, QM), (msdr.CHAIN_NO_MFMA, VALU)])
-def test_chain_q15_both_kernels_match_reference_golden(ctx, golden, mn, mode, ti, tq, flags, kernel):
-    """The matrix-core kernel (default with the Fs/4 mixer) and the VALU kernel against the reference-generated vectors."""
+def test_chain_q15_both_kernels_match_reference_golden(ctx, golden, mn, mode, ti, tq, flags, kernel, monkeypatch):
+    """The matrix-core kernel (default with the Fs/4 mixer) and the VALU kernel against the reference-generated vectors.
+    (MSDR_NO_BLOCK=1: 128-sample calls through the STREAMING kernel's cold tiles; the block kernel's turn is tests/test_gpu_block.py.)"""
+    monkeypatch.setenv("MSDR_NO_BLOCK", "1")
     sigs = ["am", "tones", "noise", "full"]
     x = np.stack([golden["chain/x_" + s] for s in sigs])
     for sk, suffix in ((msdr.SQRT_F32, ""), (msdr.SQRT_Q31, "_q31")):
@@ -688,10 +690,11 @@ def test_chain_q15_matrix_core_time_segments_and_tapsets(ctx, orc, golden):
 
 
 @pytest.mark.parametrize("mixer", [0, 1])
-def test_chain_q15_retune_mid_stream_is_bit_exact(ctx, orc, golden, mixer):
+def test_chain_q15_retune_mid_stream_is_bit_exact(ctx, orc, golden, mixer, monkeypatch):
     """msdr_chain_set_mode between calls on the Q15 chain: the FIR history (raw IF samples, mixed again at staging) and the two
     biquad nodes' state carry over, the channel groups per (tap set, demodulator) are rebuilt -- bit-exact against the oracle
     run with a carried state.  (tests/debug/fuzz_retune_q15.py is the randomised version: 56 000 plans, 0 mismatches.)"""
+    monkeypatch.setenv("MSDR_NO_BLOCK", "1")        # (one of the calls is a single block: the streaming kernel's turn here, tests/test_gpu_block.py has the block kernel's)
     rng = np.random.default_rng(90 + mixer)
     ch = 70
     pad = lambda t: np.concatenate([np.zeros(102 - t.size, np.int16), t])

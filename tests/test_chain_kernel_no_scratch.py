@@ -23,7 +23,7 @@ def code_object(tmp_path):
     subprocess.run([OBJDUMP, "--offloading", lib], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
     assert co, "no gfx950 code object inside libmsdr.so"
-    return os.path.join(tmp_path, co[0])
+    return [os.path.join(tmp_path, f) for f in sorted(co)]      # one per translation unit (msdr_api.hip, msdr_chain_block.hip)
 
 
 def kernels_of(text, needle):
@@ -42,8 +42,7 @@ def kernels_of(text, needle):
 
 @pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="library or llvm-objdump missing")
 def test_bench_flavours_of_the_wave_stream_kernel_have_no_scratch_traffic(tmp_path):
-    co = code_object(str(tmp_path))
-    text = subprocess.run([OBJDUMP, "-d", co], check=True, stdout=subprocess.PIPE, text=True).stdout
+    text = "\n".join(subprocess.run([OBJDUMP, "-d", co], check=True, stdout=subprocess.PIPE, text=True).stdout for co in code_object(str(tmp_path)))
     kernels = kernels_of(text, "chain_mfw_kernel")
     assert len(kernels) >= 10, sorted(kernels)
     # chain_mfw_kernel<2, AM, FOLD = true, FR = false>: mangled ...ILi2ELb{0,1}ELb1ELb0E...
@@ -58,8 +57,7 @@ def test_bench_flavours_of_the_wave_stream_kernel_have_no_scratch_traffic(tmp_pa
 
 @pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(READELF)), reason="library or llvm-readelf missing")
 def test_every_wave_stream_instantiation_keeps_four_waves_per_simd(tmp_path):
-    co = code_object(str(tmp_path))
-    notes = subprocess.run([READELF, "--notes", co], check=True, stdout=subprocess.PIPE, text=True).stdout
+    notes = "\n".join(subprocess.run([READELF, "--notes", co], check=True, stdout=subprocess.PIPE, text=True).stdout for co in code_object(str(tmp_path)))
     # the metadata note lists, per kernel, .name / .vgpr_count / .agpr_count
     seen = 0
     for block in notes.split(".name:")[1:]:
@@ -74,3 +72,18 @@ def test_every_wave_stream_instantiation_keeps_four_waves_per_simd(tmp_path):
         total = int(m.group(1)) + (int(a.group(1)) if a else 0)
         assert total <= 128, (name, total)
     assert seen >= 10, seen
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="library or llvm-objdump missing")
+def test_block_cadence_kernels_have_no_scratch_traffic(tmp_path):
+    """chain_mfb_kernel / chain_q15mb_kernel (msdr_chain_block.hip) run one or two waves per SIMD at up to 256 registers and prefetch the next
+    tile's window behind the matrix products: a spill there has the same cost as in the wave-stream kernels (a scratch reload waits for
+    the prefetch in front of it).  Every instantiation, no scratch instruction."""
+    text = "\n".join(subprocess.run([OBJDUMP, "-d", co], check=True, stdout=subprocess.PIPE, text=True).stdout for co in code_object(str(tmp_path)))
+    for needle, count in (("chain_mfb_kernel", 6), ("chain_q15mb_kernel", 3)):
+        kernels = kernels_of(text, needle)
+        assert len(kernels) == count, (needle, sorted(kernels))
+        for name, ins in kernels.items():
+            assert sum(1 for i in ins if i.startswith("v_mfma_")) >= 3, name
+            scratch = [i for i in ins if i.startswith("scratch_")]
+            assert not scratch, (name, scratch[:4])

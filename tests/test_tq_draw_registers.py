@@ -25,7 +25,8 @@ def disassemble(tmp_path):
     subprocess.run([OBJDUMP, "--offloading", lib], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
     assert co, "no gfx950 code object inside libmsdr.so"
-    return subprocess.run([OBJDUMP, "-d", os.path.join(tmp_path, co[0])], check=True, stdout=subprocess.PIPE, text=True).stdout
+    # (one code object per translation unit: msdr_api.hip, msdr_chain_block.hip)
+    return "\n".join(subprocess.run([OBJDUMP, "-d", os.path.join(tmp_path, f)], check=True, stdout=subprocess.PIPE, text=True).stdout for f in sorted(co))
 
 
 def parse_kernels(text):

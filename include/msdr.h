@@ -468,6 +468,25 @@ int msdr_chain_get_info(msdr_chain *chain, msdr_chain_info *info);
 int msdr_chain_enable_timing(msdr_chain *chain, int on);
 int msdr_chain_get_kernel_time(msdr_chain *chain, double *total_ms, uint64_t *launches, int reset);
 
+
+/* ---- block cadence: `ticks` consecutive calls as ONE HIP graph ------------------------------------------------------------------
+ * The reference runs one AUDIO_BLOCK_SAMPLES = 128 block per call (Minimal-SDR.ino:518-530, FIR calls :574-575); at that size a call
+ * is a few microseconds of GPU work and the host's launch cost is of the same order.  msdr_chain_graph_create records the launches
+ * of `ticks` consecutive msdr_chain_process(chain, d_if[k], d_audio[k], n_samples) calls, k = 0 .. ticks - 1, into a HIP graph on the
+ * context's stream; msdr_chain_graph_launch enqueues all of them at once (the caller refills d_if[] and collects d_audio[] between
+ * launches, ordered on the same stream).  The chain's state advances exactly as under the direct calls: direct calls, replays and
+ * live updates may follow one another -- a replay is REFUSED (MSDR_STATUS_ARGUMENT_ERROR, nothing enqueued) once a live update, a reset
+ * or an odd number of direct calls has moved what the recorded launches point at; make the graph again then.
+ *   ticks: even, 2 .. 1024 (history and cascade state alternate between two buffers from call to call).
+ *   n_samples: a block-cadence length (32, 64, 128, 256 or 512; 16-byte aligned buffers) on a chain whose call is ONE fixed set of
+ *   launches: matrix-core tables in use, no PLL / LMS channels behind the kernel, no cascade in CMSIS order behind it, no pending
+ *   oscillator change, oscillator period dividing n_samples; anything else returns MSDR_STATUS_ARGUMENT_ERROR with the reason in
+ *   msdr_last_error() and leaves the chain untouched. */
+typedef struct msdr_chain_graph msdr_chain_graph;
+int msdr_chain_graph_create(msdr_chain *chain, uint32_t ticks, const int16_t *const *d_if, void *const *d_audio, uint64_t n_samples, msdr_chain_graph **out);
+int msdr_chain_graph_launch(msdr_chain_graph *graph);
+int msdr_chain_graph_destroy(msdr_chain_graph *graph);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1980,6 +1980,7 @@ struct msdr_chain {
     // what the per-call kernel choice needs to know about the channels' modes / tap sets / LMS switches, recomputed when they change (a
     // call at block cadence must not walk 65 536 channels on the host)
     struct Summary { uint64_t mode_gen = 0, anr_gen = 0; bool any_ssb = false, any_env = false, any_syncam = false, qm_sets_ok = true, any_anr = false; } sum;
+    bool dry_run = false;                // msdr_chain_graph_create: msdr_chain_process prepares a block-cadence call (tables, caches) and returns before its launches
     bool block_off = false;              // MSDR_NO_BLOCK=1 at create time: keep the wave-stream kernels at every call length (A/B runs, tests)
     std::vector<std::vector<float>> h_coef_i, h_coef_q;   // host copies for msdr_chain_set_mode
     std::vector<double> h_osc, h_cnum;                    // oscillator pairs {cos, sin}; combined numerator
@@ -3212,6 +3213,17 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
 #endif
     }
 
+    if (c->dry_run) {
+        // msdr_chain_graph_create's preparation pass: everything a block-cadence call needs from the host is in place now; say whether the
+        // launches that follow are fixed (capturable into a HIP graph) -- and make none
+        if (!use_mfb && !use_qb) return fail(MSDR_STATUS_ARGUMENT_ERROR, "not a block-cadence call (32 .. 512 samples, a divisor of 1024, 16-byte aligned buffers, matrix-core tables, no pending oscillator change): nothing to capture");
+        if (c->seq_bq) return fail(MSDR_STATUS_ARGUMENT_ERROR, "the cascade runs in CMSIS order behind the kernel (a kernel of its own with host-side sizing): not capturable");
+        if (i16_via_scratch) return fail(MSDR_STATUS_ARGUMENT_ERROR, "int16 audio through the scratch batch: not capturable");
+        if (f32 && (c->f32_pll || c->aux || chain_summary(c).any_anr)) return fail(MSDR_STATUS_ARGUMENT_ERROR, "PLL / LMS channels run behind the kernel through an auxiliary chain: not capturable");
+        if (!f32 && c->anr && (c->d_anr_on || c->anr_all > 0)) return fail(MSDR_STATUS_ARGUMENT_ERROR, "the LMS filter runs behind the kernel: not capturable");
+        if (n_samples % c->osc_len) return fail(MSDR_STATUS_ARGUMENT_ERROR, "the oscillator's position changes from call to call at this block length: not capturable");
+        return 0;
+    }
     const size_t lds = use_mfw ? mw_lds_bytes(c->mf_halo, c->mf_bsteps, c->mfw_nw, c->mf_fr) : use_fold ? fold_lds_bytes(p.ntaps_pad) : chain_lds_bytes(p.ntaps_pad);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && c->events.size() < 8192) {
@@ -3445,6 +3457,97 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     c->info.time_segments = (uint32_t)nseg; c->info.warmup = (uint32_t)p.warm; c->info.tile = (uint32_t)kTile;
     c->info.taps_padded = c->ntaps_pad;
     c->info.mfma_ksteps = use_mf ? (uint32_t)c->mf_bsteps : use_qm ? (uint32_t)c->qm_bsteps : 0u;
+    return 0;
+}
+
+// ---- msdr_chain_graph_*: `ticks` consecutive block-cadence calls as ONE HIP graph ------------------------------------------------------------
+// At the reference's cadence (one 128-sample block per call, Minimal-SDR.ino:518-530) a call is 7 - 10 us of GPU work behind 3 - 5 us of host
+// work per launch; a graph replay enqueues `ticks` calls for the price of one.  The chain's history and cascade state alternate between two
+// buffers from call to call, so a graph holds an EVEN number of calls: after a replay the host's record of which buffer is current is what it
+// was, and direct calls, live updates and replays can follow one another in any order.
+struct msdr_chain_graph {
+    msdr_chain *c;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    uint32_t ticks;
+    uint64_t n;
+    // what the captured launches point at: a replay is refused once any of it has moved (a live update rebuilt the tables, a call of
+    // another length ran in between an odd number of times, the chain was reset)
+    const void *k_hist, *k_state, *k_tab, *k_tiles;
+    int k_cur;
+    uint64_t k_mode_gen;
+};
+static void chain_graph_key(const msdr_chain *c, msdr_chain_graph *g)
+{
+    g->k_hist = c->d_hist[c->cur]; g->k_state = c->d_bq_state; g->k_tab = c->arith == MSDR_ARITH_F32 ? (const void *)c->d_mf_tab : (const void *)c->d_qm_tab;
+    g->k_tiles = c->d_btiles; g->k_cur = c->cur; g->k_mode_gen = c->mode_gen;
+}
+
+extern "C" int msdr_chain_graph_create(msdr_chain *c, uint32_t ticks, const int16_t *const *d_if, void *const *d_audio, uint64_t n_samples, msdr_chain_graph **out)
+{
+    if (!out) return fail(MSDR_STATUS_ARGUMENT_ERROR, "out is null");
+    *out = nullptr;
+    if (!c || !d_if || !d_audio) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null argument");
+    if (int rc = bind(c->ctx)) return rc;
+    if (ticks < 2 || (ticks & 1u) || ticks > 1024) return fail(MSDR_STATUS_ARGUMENT_ERROR, "a chain graph holds an even number of calls, 2 .. 1024 (the state buffers alternate from call to call)");
+    for (uint32_t k = 0; k < ticks; k++) if (!d_if[k] || !d_audio[k]) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null buffer for call %u", k);
+    // 1. preparation: every table / cache a call of this shape needs, built outside the capture (uploads and synchronisations are not
+    //    capturable); the same pass says whether the call's launches are fixed
+    const bool timing = c->timing;
+    c->timing = false; c->dry_run = true;
+    int rc = 0;
+    for (uint32_t k = 0; k < ticks && !rc; k++) rc = msdr_chain_process(c, d_if[k], d_audio[k], n_samples);      // (alignment is per buffer)
+    c->dry_run = false;
+    if (rc) { c->timing = timing; return rc; }
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    // 2. capture: the launches of `ticks` calls.  The host's bookkeeping runs with them (an even number of flips: back where it was).
+    const int cur0 = c->cur; const uint64_t gen0 = c->gen; const long long phase0 = c->phase;
+    float *const st0 = c->d_bq_state, *const st1 = c->d_bq_state_alt;
+    msdr_chain_graph *g = new (std::nothrow) msdr_chain_graph();
+    if (!g) { c->timing = timing; return fail(MSDR_STATUS_OUT_OF_MEMORY, "host allocation failed"); }
+    g->c = c; g->graph = nullptr; g->exec = nullptr; g->ticks = ticks; g->n = n_samples;
+    chain_graph_key(c, g);
+    if (hipStreamBeginCapture(c->ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { delete g; c->timing = timing; return fail(MSDR_STATUS_HIP_ERROR, "hipStreamBeginCapture failed"); }
+    for (uint32_t k = 0; k < ticks && !rc; k++) rc = msdr_chain_process(c, d_if[k], d_audio[k], n_samples);
+    const std::string why = rc ? g_err : std::string();
+    const hipError_t ee = hipStreamEndCapture(c->ctx->stream, &g->graph);
+    c->timing = timing;
+    c->cur = cur0; c->gen = gen0; c->phase = phase0; c->d_bq_state = st0; c->d_bq_state_alt = st1;        // (nothing ran: the stream is where it was)
+    if (rc || ee != hipSuccess || !g->graph) {
+        if (g->graph) hipGraphDestroy(g->graph);
+        delete g;
+        (void)hipGetLastError();
+        return rc ? fail(rc, "capture of a chain call failed: %s", why.c_str()) : fail(MSDR_STATUS_HIP_ERROR, "hipStreamEndCapture failed");
+    }
+    if (hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) {
+        hipGraphDestroy(g->graph); delete g;
+        return fail(MSDR_STATUS_HIP_ERROR, "hipGraphInstantiate failed");
+    }
+    *out = g;
+    return 0;
+}
+
+extern "C" int msdr_chain_graph_launch(msdr_chain_graph *g)
+{
+    if (!g || !g->c) return fail(MSDR_STATUS_ARGUMENT_ERROR, "null graph");
+    msdr_chain *c = g->c;
+    if (int rc = bind(c->ctx)) return rc;
+    msdr_chain_graph now;
+    chain_graph_key(c, &now);
+    if (now.k_hist != g->k_hist || now.k_state != g->k_state || now.k_tab != g->k_tab || now.k_tiles != g->k_tiles || now.k_cur != g->k_cur || now.k_mode_gen != g->k_mode_gen)
+        return fail(MSDR_STATUS_ARGUMENT_ERROR, "the chain has changed since this graph was made (a live update, a reset, or an odd number of direct calls in between): make the graph again");
+    HIP_TRY(hipGraphLaunch(g->exec, c->ctx->stream));
+    c->gen += g->ticks;                                     // (an even number of calls: buffers, table position and caches stay as they are)
+    return 0;
+}
+
+extern "C" int msdr_chain_graph_destroy(msdr_chain_graph *g)
+{
+    if (!g) return 0;
+    if (g->c) (void)bind(g->c->ctx);
+    if (g->exec) hipGraphExecDestroy(g->exec);
+    if (g->graph) hipGraphDestroy(g->graph);
+    delete g;
     return 0;
 }
 

@@ -90,6 +90,9 @@ def load_library(path=None):
         _lib.msdr_memset.argtypes = [_p, _p, C.c_int, C.c_size_t]
         _lib.msdr_ctx_create.argtypes = [C.c_int, _p, _p]
         _lib.msdr_chain_process.argtypes = [_p, _p, _p, C.c_uint64]
+        _lib.msdr_chain_graph_create.argtypes = [_p, C.c_uint32, _p, _p, C.c_uint64, _p]
+        _lib.msdr_chain_graph_launch.argtypes = [_p]
+        _lib.msdr_chain_graph_destroy.argtypes = [_p]
         _lib.msdr_chain_get_kernel_time.argtypes = [_p, _p, _p, C.c_int]
         for n in ("msdr_fir_q15_process", "msdr_fir_f32_process", "msdr_biquad_df1_f32_process"):
             getattr(_lib, n).argtypes = [_p, _p, _p, C.c_uint32]
@@ -550,6 +553,26 @@ def amp_q15(ctx, multiplier, d_data, channels, n):
     return bool(t.value)
 
 
+class ChainGraph:
+    """`ticks` consecutive block-cadence calls of one chain as ONE HIP graph (include/msdr.h: msdr_chain_graph_*)."""
+
+    def __init__(self, chain, d_ifs, d_audios, n):
+        assert len(d_ifs) == len(d_audios)
+        self.chain, self.ticks = chain, len(d_ifs)
+        pi = (C.c_void_p * self.ticks)(*[(d.ptr if hasattr(d, "ptr") else int(d)) for d in d_ifs])
+        po = (C.c_void_p * self.ticks)(*[(d.ptr if hasattr(d, "ptr") else int(d)) for d in d_audios])
+        self.h = C.c_void_p()
+        _ck(chain.ctx.lib.msdr_chain_graph_create(chain.h, self.ticks, pi, po, n, C.byref(self.h)))
+
+    def launch(self):
+        _ck(self.chain.ctx.lib.msdr_chain_graph_launch(self.h))
+
+    def close(self):
+        if self.h:
+            self.chain.ctx.lib.msdr_chain_graph_destroy(self.h)
+            self.h = None
+
+
 class Chain(_Instance):
     """The fused chain (msdr_chain_*): demodulation() + the biquad nodes behind it."""
     _destroy = "msdr_chain_destroy"
@@ -603,6 +626,10 @@ class Chain(_Instance):
         pi = d_if.ptr if hasattr(d_if, "ptr") else int(d_if)
         po = d_audio.ptr if hasattr(d_audio, "ptr") else int(d_audio)
         _ck(self.ctx.lib.msdr_chain_process(self.h, pi, po, n))
+
+    def graph(self, d_ifs, d_audios, n):
+        """msdr_chain_graph_create: len(d_ifs) (even) consecutive calls of n samples as one HIP graph; .launch() enqueues them."""
+        return ChainGraph(self, d_ifs, d_audios, n)
 
     def reset(self):
         _ck(self.ctx.lib.msdr_chain_reset(self.h))

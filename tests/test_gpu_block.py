@@ -398,3 +398,98 @@ def test_block_q15_live_tap_and_node_updates(ctx, orc):
         chain.process(dx, dy, 128)
         got[:, t * 128:(t + 1) * 128] = dy.download()
         assert _is_qblock(chain), chain.info()["kernel"]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# msdr_chain_graph_*: an even number of consecutive block-cadence calls as one HIP graph
+# ------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("arith", ["f32", "q15"])
+@pytest.mark.parametrize("ticks_per_graph", [2, 8])
+def test_chain_graph_replays_equal_direct_calls(ctx, orc, golden, arith, ticks_per_graph):
+    """64+ ticks as replays of one graph (the caller refills the graph's input buffers between replays), with direct calls and a live
+    update in between: the audio equals the oracle's over the whole stream -- bit-exact (Q15) / <= 1e-5 (fp32)."""
+    rng = np.random.default_rng(700 + ticks_per_graph)
+    ch, T = 24, ticks_per_graph
+    replays = 64 // T
+    lp_a, lp_b = _lowpass(102, 2800.0), _lowpass(102, 1700.0)
+    if arith == "q15":
+        lpn, ntn = _ref_nodes(orc)
+        ta, tb = orc.calc_fir_coeffs(102, 2800.0)[:102].copy(), orc.calc_fir_coeffs(102, 1700.0)[:102].copy()
+        chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, ta, ta, mode=orclib.AM, biquad_nodes=[[lpn], [ntn]])
+        out_t = np.int16
+    else:
+        bq = _f32_biquads(orc, 2)
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, lp_a, lp_a, mixer=msdr.MIXER_FS4, mode=orclib.AM, biquad_coeffs=bq)
+        out_t = np.float32
+    n_total = (replays * T + 4 + T + (replays - 1) * T) * 128    # replays | 3 + 1 direct calls | one replay | a tap change | replays
+    x = rng.integers(-12000, 12001, (ch, n_total)).astype(np.int16)
+    dxs, dys = [ctx.array((ch, 128), np.int16) for _ in range(T)], [ctx.array((ch, 128), out_t) for _ in range(T)]
+    got = np.empty((ch, n_total), out_t)
+    o = 0
+
+    def run_graph(g, times):
+        nonlocal o
+        for _ in range(times):
+            for k in range(T):
+                dxs[k].upload(x[:, o + 128 * k:o + 128 * (k + 1)])
+            g.launch()
+            for k in range(T):
+                got[:, o + 128 * k:o + 128 * (k + 1)] = dys[k].download()
+            o += 128 * T
+
+    def direct(times):
+        nonlocal o
+        for _ in range(times):
+            dx, dy = ctx.to_device(x[:, o:o + 128]), ctx.array((ch, 128), out_t)
+            chain.process(dx, dy, 128)
+            got[:, o:o + 128] = dy.download()
+            o += 128
+
+    g = chain.graph(dxs, dys, 128)
+    run_graph(g, replays)
+    direct(3)                                                   # an odd number of direct calls: the buffers the graph points at are the other pair now
+    with pytest.raises(msdr.MsdrError):
+        g.launch()
+    direct(1)                                                   # even again: the old graph is valid once more
+    run_graph(g, 1)
+    change_at = o
+    if arith == "q15":
+        chain.set_taps(0, tb, tb)
+    else:
+        chain.set_taps(0, lp_b, lp_b)
+    with pytest.raises(msdr.MsdrError):                        # the tables moved: make the graph again
+        g.launch()
+    g.close()
+    g = chain.graph(dxs, dys, 128)
+    run_graph(g, replays - 1)
+    g.close()
+    assert o <= x.shape[1]
+    for c in range(0, ch, 5):
+        st = {}
+        if arith == "q15":
+            nodes = [orc.biquad_teensy_new([lpn]), orc.biquad_teensy_new([ntn])]
+            w1 = orc.chain_q15(x[c, :change_at], orclib.AM, ta, ta, biquads=nodes, state=st)
+            w2 = orc.chain_q15(x[c, change_at:o], orclib.AM, tb, tb, biquads=nodes, state=st)
+            assert np.array_equal(got[c, :o], np.concatenate([w1, w2])), c
+        else:
+            w1 = orc.chain_f32(x[c, :change_at], orclib.AM, lp_a, lp_a, SIN4, COS4, bq, state=st)
+            w2 = orc.chain_f32(x[c, change_at:o], orclib.AM, lp_b, lp_b, SIN4, COS4, bq, state=st)
+            assert rel_rms(got[c, :change_at], w1) < TOL and rel_rms(got[c, change_at:o], w2) < TOL, c
+
+
+def test_chain_graph_refuses_what_it_cannot_hold(ctx, orc):
+    lp = _lowpass(102)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 8, lp, lp, mixer=msdr.MIXER_FS4, mode=orclib.AM)
+    dx, dy = [ctx.array((8, 128), np.int16) for _ in range(3)], [ctx.array((8, 128), np.float32) for _ in range(3)]
+    with pytest.raises(msdr.MsdrError):
+        chain.graph(dx, dy, 128)                               # an odd number of calls
+    with pytest.raises(msdr.MsdrError):
+        chain.graph(dx[:2], dy[:2], 100)                       # not a block-cadence length
+    big_x, big_y = [ctx.array((8, 4096), np.int16) for _ in range(2)], [ctx.array((8, 4096), np.float32) for _ in range(2)]
+    with pytest.raises(msdr.MsdrError):
+        chain.graph(big_x, big_y, 4096)                        # the streaming kernel's calls are not recorded
+    g = chain.graph(dx[:2], dy[:2], 128)
+    g.launch()
+    g.close()
+    # a chain left untouched by the refusals: a direct call still works from the state the one replay left
+    chain.process(dx[0], dy[0], 128)

@@ -17,6 +17,8 @@
  *     biquad cascade keeps arm_biquad_cascade_df1_f32's pState semantics across the change, msdr_biquad_df1_f32_set_coeffs).  A
  *     re-run of the init zeroes the state, as init_FIR() does on every retune (Minimal-SDR.ino:901-930).  The caller-owned pState
  *     is cleared as the reference's init does and is otherwise unused (the state lives on the device).
+ *   * a rebuild that fails (a cascade whose state cannot be carried to the new coefficients, an allocation) leaves the filter on its old
+ *     tables for this call -- pDst is still written -- and is tried again on the next call; msdr_last_error() has the text.
  *   * errors: the init keeps arm_fir_init_q15's contract (odd numTaps -> ARM_MATH_ARGUMENT_ERROR, instance left untouched,
  *     arm_fir_init_q15.c:93-96); the void process functions cannot report anything -- msdr_last_error() has the text.
  * Define MSDR_CMSIS_NAMES before including this header to get the arm_* names themselves as macros. */
@@ -39,6 +41,12 @@ typedef struct { uint32_t numStages; float32_t *pState; float32_t *pCoeffs; } ms
 
 /* the context and batch width the shims below work with; NULL unbinds and frees every instance created through them */
 int msdr_cmsis_bind(msdr_ctx *ctx, uint32_t channels);
+/* The same with pSrc / pDst as HOST arrays of [channels][blockSize] samples -- what the sketch passes: `arm_fir_fast_q15(&FIR_I, I_buffer,
+ * I_FIR_out, AUDIO_BLOCK_SAMPLES)` on stack arrays (Minimal-SDR.ino:525-526, 574-575); channels = 1 is exactly that call.  Every process
+ * call stages the block through two device buffers on the context's stream and returns when pDst holds the result (a PCIe round trip per
+ * call: the drop-in for a sketch that keeps its buffers where they are; a caller that cares for throughput keeps them on the device and
+ * binds with msdr_cmsis_bind). */
+int msdr_cmsis_bind_host(msdr_ctx *ctx, uint32_t channels);
 
 msdr_arm_status msdr_arm_fir_init_q15(msdr_arm_fir_instance_q15 *S, uint16_t numTaps, q15_t *pCoeffs, q15_t *pState, uint32_t blockSize);
 void msdr_arm_fir_fast_q15(const msdr_arm_fir_instance_q15 *S, q15_t *pSrc, q15_t *pDst, uint32_t blockSize);

@@ -1148,6 +1148,9 @@ extern "C" int msdr_biquad_df1_f32_cascade_info(uint8_t numStages, const float32
     if (cmsis_order) *cmsis_order = (numStages && cascade_needs_cmsis_order(pCoeffs, (int)numStages)) ? 1 : 0;
     return 0;
 }
+// set around msdr_biquad_df1_f32_create by a chain that must have its cascade in CMSIS order whatever the conditioning figures say
+// (three or more sections behind chain_kernel<ArithF32>: chain_create_impl)
+static thread_local bool g_biquad_force_sequential = false;
 extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, const float32_t *pCoeffs, uint32_t channels,
                                           msdr_biquad_df1_f32 **out)
 {
@@ -1161,7 +1164,7 @@ extern "C" int msdr_biquad_df1_f32_create(msdr_ctx *ctx, uint8_t numStages, cons
     S->ctx = ctx; S->channels = channels; S->stages = numStages; S->d_tabs = nullptr; S->d_state = nullptr; S->d_state_alt = nullptr;
     S->pole_radius = numStages ? max_pole_radius(pCoeffs, (int)numStages) : 0.0;
     S->d_coeffs = nullptr; S->d_seq_scratch = nullptr; S->seq_scratch_floats = 0;
-    S->sequential = numStages > 0 && cascade_needs_cmsis_order(pCoeffs, (int)numStages);
+    S->sequential = numStages > 0 && (g_biquad_force_sequential || cascade_needs_cmsis_order(pCoeffs, (int)numStages));
     S->seq_segments = true;
     if (numStages) S->h_coeffs.assign(pCoeffs, pCoeffs + 5 * numStages);
     if (S->sequential) {
@@ -2104,15 +2107,17 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
 
     if (f32 && cfg->num_biquad_stages &&
         (g_chain_force_seq_cascade || cascade_needs_cmsis_order(cfg->biquad_coeffs, (int)cfg->num_biquad_stages))) {
+        const bool forced = g_chain_force_seq_cascade;            // (the stage object below must then be the CMSIS-order one too: it decides for itself otherwise)
         g_chain_force_seq_cascade = false;
         // the parallel "numerators first" evaluation would lose accuracy on this cascade (cascade_condition): build the chain without
         // it and run arm_biquad_cascade_df1_f32 as written behind the main kernel (one lane per channel)
         msdr_chain_config plain = *cfg;
         plain.num_biquad_stages = 0; plain.biquad_coeffs = nullptr;
         if (int rc = chain_create_impl(ctx, &plain, out)) return rc;
-        if (int rc = msdr_biquad_df1_f32_create(ctx, (uint8_t)cfg->num_biquad_stages, cfg->biquad_coeffs, cfg->channels, &(*out)->seq_bq)) {
-            msdr_chain_destroy(*out); *out = nullptr; return rc;
-        }
+        g_biquad_force_sequential = forced;
+        const int rcb = msdr_biquad_df1_f32_create(ctx, (uint8_t)cfg->num_biquad_stages, cfg->biquad_coeffs, cfg->channels, &(*out)->seq_bq);
+        g_biquad_force_sequential = false;
+        if (rcb) { msdr_chain_destroy(*out); *out = nullptr; return rcb; }
         (*out)->h_bq.assign(cfg->biquad_coeffs, cfg->biquad_coeffs + 5 * cfg->num_biquad_stages); (*out)->h_bq_stages = cfg->num_biquad_stages;
         return 0;
     }
@@ -3452,7 +3457,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             if (int rc = chain_leave_generic(c)) return rc;
     }
 
-    snprintf(c->info.kernel, sizeof c->info.kernel, "%s%s", kname, c->seq_bq ? " + biquad_df1_seq_kernel" : "");
+    snprintf(c->info.kernel, sizeof c->info.kernel, "%s%s", kname, !c->seq_bq ? "" : c->seq_bq->sequential ? " + biquad_df1_seq_kernel" : " + biquad_df1_kernel");
     c->info.grid = grid; c->info.block = block; c->info.lds_bytes = (uint32_t)lds_used;
     c->info.time_segments = (uint32_t)nseg; c->info.warmup = (uint32_t)p.warm; c->info.tile = (uint32_t)kTile;
     c->info.taps_padded = c->ntaps_pad;
@@ -3890,6 +3895,9 @@ extern "C" int msdr_chain_set_biquad_coeffs(msdr_chain *c, const float32_t *coef
     std::vector<int16_t> hist((size_t)c->channels * c->hist_len);
     HIP_TRY(hipMemcpy(hist.data(), c->d_hist[c->cur], hist.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
     if (c->seq_bq) {
+        // (a stage object that runs block-parallel keeps its state in the coefficient-dependent basis too: the same refusal applies --
+        //  build_to() leaves its matrices zero on failure, and reading through them would silently zero the filter's state)
+        if (!c->seq_bq->sequential && !br.ok_to) return fail(MSDR_STATUS_ARGUMENT_ERROR, "the running cascade's block-parallel state has no unique CMSIS state (a numerator shares a root with an earlier denominator)");
         if (int rc = biquad_df1_read_cmsis(c->seq_bq, br, Y, D)) return rc;
     } else {
         if (!br.ok_to) return fail(MSDR_STATUS_ARGUMENT_ERROR, "the running cascade's block-parallel state has no unique CMSIS state (a numerator shares a root with an earlier denominator)");

@@ -18,6 +18,11 @@ struct Binding {
     msdr_ctx *ctx = nullptr;
     uint32_t channels = 0;
     std::unordered_map<const void *, Entry> inst;  // keyed by the caller's instance struct, as CMSIS identifies a filter
+    // msdr_cmsis_bind_host: pSrc / pDst are HOST arrays (the sketch's stack buffers, Minimal-SDR.ino:525-526, 574-575), staged through two
+    // device buffers that grow with the largest block seen
+    bool host = false;
+    void *d_in = nullptr, *d_out = nullptr;
+    size_t cap = 0;
 };
 Binding &binding() { static Binding b; return b; }
 
@@ -52,12 +57,37 @@ Entry *lookup_locked(const void *S, int kind)
     auto it = b.inst.find(S);
     return (it != b.inst.end() && it->second.kind == kind) ? &it->second : nullptr;
 }
-// the caller's coefficient array against the snapshot; true = changed (and the snapshot now holds the new bytes)
-bool coeffs_changed(Entry *e, const void *pCoeffs)
+// The caller's coefficient array against the snapshot.  On a change the tables are rebuilt through `set` (state kept); the snapshot takes
+// the new bytes only once that has SUCCEEDED -- after a failed rebuild (a cascade whose state cannot cross to the new coefficients, an
+// allocation that failed) the old snapshot stays, so the next call compares unequal again and retries, and this call runs the filter with
+// the tables it still has (pDst is written either way; msdr_last_error() has the text of the failure).
+template <typename Set>
+void follow_coeffs(Entry *e, const void *pCoeffs, Set &&set)
 {
-    if (!pCoeffs || e->coef.empty() || memcmp(e->coef.data(), pCoeffs, e->coef.size()) == 0) return false;
-    memcpy(e->coef.data(), pCoeffs, e->coef.size());
-    return true;
+    if (!pCoeffs || e->coef.empty() || memcmp(e->coef.data(), pCoeffs, e->coef.size()) == 0) return;
+    if (set() == 0) memcpy(e->coef.data(), pCoeffs, e->coef.size());
+}
+void drop_staging(Binding &b)
+{
+    if (b.ctx) { if (b.d_in) msdr_free(b.ctx, b.d_in); if (b.d_out) msdr_free(b.ctx, b.d_out); }
+    b.d_in = b.d_out = nullptr; b.cap = 0;
+}
+// host-array binding: the block batch [channels][blockSize] of `esz`-byte samples goes host -> device -> `run` -> device -> host; the
+// call returns when pDst holds the result, as the CMSIS function does.  Device-pointer binding: `run` on the caller's pointers.
+template <typename Run>
+void with_buffers(Binding &b, const void *pSrc, void *pDst, uint32_t blockSize, size_t esz, Run &&run)
+{
+    if (!b.host) { (void)run(pSrc, pDst); return; }
+    const size_t bytes = (size_t)b.channels * blockSize * esz;
+    if (bytes == 0 || !pSrc || !pDst) return;
+    if (bytes > b.cap) {
+        drop_staging(b);
+        if (msdr_malloc(b.ctx, bytes, &b.d_in) != 0 || msdr_malloc(b.ctx, bytes, &b.d_out) != 0) { drop_staging(b); return; }
+        b.cap = bytes;
+    }
+    if (msdr_memcpy_h2d(b.ctx, b.d_in, pSrc, bytes) != 0) return;
+    if (run(b.d_in, b.d_out) != 0) return;
+    (void)msdr_memcpy_d2h(b.ctx, pDst, b.d_out, bytes);
 }
 
 }  // namespace
@@ -71,18 +101,22 @@ __attribute__((visibility("hidden"))) void msdr_cmsis_ctx_gone(msdr_ctx *ctx)
     if (b.ctx != ctx) return;
     for (auto &kv : b.inst) destroy(kv.second);
     b.inst.clear();
-    b.ctx = nullptr; b.channels = 0;
+    drop_staging(b);
+    b.ctx = nullptr; b.channels = 0; b.host = false;
 }
 
-extern "C" int msdr_cmsis_bind(msdr_ctx *ctx, uint32_t channels)
+static int bind_common(msdr_ctx *ctx, uint32_t channels, bool host)
 {
     Binding &b = binding();
     std::lock_guard<std::mutex> g(b.mu);
     for (auto &kv : b.inst) destroy(kv.second);    // objects of the previous binding go with it
     b.inst.clear();
-    b.ctx = ctx; b.channels = ctx ? channels : 0;
+    drop_staging(b);
+    b.ctx = ctx; b.channels = ctx ? channels : 0; b.host = ctx ? host : false;
     return (ctx && channels == 0) ? MSDR_STATUS_ARGUMENT_ERROR : MSDR_STATUS_SUCCESS;
 }
+extern "C" int msdr_cmsis_bind(msdr_ctx *ctx, uint32_t channels) { return bind_common(ctx, channels, false); }
+extern "C" int msdr_cmsis_bind_host(msdr_ctx *ctx, uint32_t channels) { return bind_common(ctx, channels, true); }
 
 extern "C" msdr_arm_status msdr_arm_fir_init_q15(msdr_arm_fir_instance_q15 *S, uint16_t numTaps, q15_t *pCoeffs, q15_t *pState, uint32_t blockSize)
 {
@@ -101,8 +135,8 @@ extern "C" void msdr_arm_fir_fast_q15(const msdr_arm_fir_instance_q15 *S, q15_t 
     std::lock_guard<std::mutex> g(binding().mu);
     Entry *e = lookup_locked(S, 0);
     if (!e) return;
-    if (coeffs_changed(e, S->pCoeffs) && msdr_fir_q15_set_coeffs((msdr_fir_q15 *)e->handle, S->pCoeffs) != 0) return;
-    (void)msdr_fir_q15_process((msdr_fir_q15 *)e->handle, pSrc, pDst, blockSize);
+    follow_coeffs(e, S->pCoeffs, [&] { return msdr_fir_q15_set_coeffs((msdr_fir_q15 *)e->handle, S->pCoeffs); });
+    with_buffers(binding(), pSrc, pDst, blockSize, sizeof(q15_t), [&](const void *src, void *dst) { return msdr_fir_q15_process((msdr_fir_q15 *)e->handle, (const q15_t *)src, (q15_t *)dst, blockSize); });
 }
 
 extern "C" void msdr_arm_fir_init_f32(msdr_arm_fir_instance_f32 *S, uint16_t numTaps, float32_t *pCoeffs, float32_t *pState, uint32_t blockSize)
@@ -120,8 +154,8 @@ extern "C" void msdr_arm_fir_f32(const msdr_arm_fir_instance_f32 *S, float32_t *
     std::lock_guard<std::mutex> g(binding().mu);
     Entry *e = lookup_locked(S, 1);
     if (!e) return;
-    if (coeffs_changed(e, S->pCoeffs) && msdr_fir_f32_set_coeffs((msdr_fir_f32 *)e->handle, S->pCoeffs) != 0) return;
-    (void)msdr_fir_f32_process((msdr_fir_f32 *)e->handle, pSrc, pDst, blockSize);
+    follow_coeffs(e, S->pCoeffs, [&] { return msdr_fir_f32_set_coeffs((msdr_fir_f32 *)e->handle, S->pCoeffs); });
+    with_buffers(binding(), pSrc, pDst, blockSize, sizeof(float32_t), [&](const void *src, void *dst) { return msdr_fir_f32_process((msdr_fir_f32 *)e->handle, (const float32_t *)src, (float32_t *)dst, blockSize); });
 }
 
 extern "C" void msdr_arm_biquad_cascade_df1_init_f32(msdr_arm_biquad_casd_df1_inst_f32 *S, uint8_t numStages, float32_t *pCoeffs, float32_t *pState)
@@ -139,6 +173,6 @@ extern "C" void msdr_arm_biquad_cascade_df1_f32(const msdr_arm_biquad_casd_df1_i
     std::lock_guard<std::mutex> g(binding().mu);
     Entry *e = lookup_locked(S, 2);
     if (!e) return;
-    if (coeffs_changed(e, S->pCoeffs) && msdr_biquad_df1_f32_set_coeffs((msdr_biquad_df1_f32 *)e->handle, S->pCoeffs) != 0) return;
-    (void)msdr_biquad_df1_f32_process((msdr_biquad_df1_f32 *)e->handle, pSrc, pDst, blockSize);
+    follow_coeffs(e, S->pCoeffs, [&] { return msdr_biquad_df1_f32_set_coeffs((msdr_biquad_df1_f32 *)e->handle, S->pCoeffs); });
+    with_buffers(binding(), pSrc, pDst, blockSize, sizeof(float32_t), [&](const void *src, void *dst) { return msdr_biquad_df1_f32_process((msdr_biquad_df1_f32 *)e->handle, (const float32_t *)src, (float32_t *)dst, blockSize); });
 }

@@ -323,6 +323,7 @@ class FirQ15(_Instance):
     def __init__(self, ctx, coeffs, channels):
         self.ctx = ctx
         c = np.ascontiguousarray(coeffs, np.int16)
+        self.ntaps = int(c.size)
         h = _p()
         _ck(ctx.lib.msdr_fir_q15_create(ctx.h, C.c_uint16(c.size), _hp(c), C.c_uint32(channels), C.byref(h)))
         self.h = h
@@ -336,6 +337,8 @@ class FirQ15(_Instance):
     def set_coeffs(self, coeffs):
         """pCoeffs rewritten under the running filter (UI.cpp:337-345): state kept."""
         c = np.ascontiguousarray(coeffs, np.int16)
+        if c.size != self.ntaps:
+            raise ValueError("set_coeffs: %d taps given, the instance has %d" % (c.size, self.ntaps))
         _ck(self.ctx.lib.msdr_fir_q15_set_coeffs(self.h, _hp(c)))
 
 
@@ -346,6 +349,7 @@ class FirF32(_Instance):
     def __init__(self, ctx, coeffs, channels):
         self.ctx = ctx
         c = np.ascontiguousarray(coeffs, np.float32)
+        self.ntaps = int(c.size)
         h = _p()
         _ck(ctx.lib.msdr_fir_f32_create(ctx.h, C.c_uint16(c.size), _hp(c), C.c_uint32(channels), C.byref(h)))
         self.h = h
@@ -358,6 +362,8 @@ class FirF32(_Instance):
 
     def set_coeffs(self, coeffs):
         c = np.ascontiguousarray(coeffs, np.float32)
+        if c.size != self.ntaps:
+            raise ValueError("set_coeffs: %d taps given, the instance has %d" % (c.size, self.ntaps))
         _ck(self.ctx.lib.msdr_fir_f32_set_coeffs(self.h, _hp(c)))
 
     def set_input_range(self, max_abs):
@@ -377,6 +383,7 @@ class BiquadDf1F32(_Instance):
     def __init__(self, ctx, coeffs, channels):
         self.ctx = ctx
         c = np.ascontiguousarray(coeffs, np.float32).reshape(-1)
+        self.stages = int(c.size // 5)
         h = _p()
         _ck(ctx.lib.msdr_biquad_df1_f32_create(ctx.h, C.c_uint8(c.size // 5), _hp(c) if c.size else None,
                                                C.c_uint32(channels), C.byref(h)))
@@ -391,6 +398,8 @@ class BiquadDf1F32(_Instance):
     def set_coeffs(self, coeffs):
         """pCoeffs rewritten under the running cascade: continues from CMSIS' pState."""
         c = np.ascontiguousarray(coeffs, np.float32).reshape(-1)
+        if c.size != 5 * self.stages:
+            raise ValueError("set_coeffs: %d values given, the cascade has %d stages x 5" % (c.size, self.stages))
         _ck(self.ctx.lib.msdr_biquad_df1_f32_set_coeffs(self.h, _hp(c)))
 
     def cmsis_state(self, channel, stages):
@@ -589,6 +598,7 @@ class Chain(_Instance):
         cfg.struct_size = C.sizeof(ChainConfig)
         cfg.arith, cfg.channels, cfg.mixer = arith, channels, mixer
         cfg.num_taps, cfg.num_tapsets = ci[0].size, len(ci)
+        self.ntaps, self.osc_len, self.stages = int(ci[0].size), 0, 0     # what the setters' arrays must hold (the C side copies that many elements)
         for k in range(len(ci)):
             cfg.coeffs_i[k], cfg.coeffs_q[k] = _hp(ci[k]), _hp(cq[k])
         cfg.default_mode = mode
@@ -605,11 +615,13 @@ class Chain(_Instance):
             oi, oq = np.ascontiguousarray(osc_i, tdt), np.ascontiguousarray(osc_q, tdt)
             keep += [oi, oq]
             cfg.osc_len, cfg.osc_i, cfg.osc_q = oi.size, _hp(oi), _hp(oq)
+            self.osc_len = int(oi.size)
         cfg.in_scale = in_scale
         if biquad_coeffs is not None and arith == ARITH_F32:
             b = np.ascontiguousarray(biquad_coeffs, np.float32).reshape(-1)
             keep.append(b)
             cfg.num_biquad_stages, cfg.biquad_coeffs = b.size // 5, _hp(b)
+            self.stages = int(b.size // 5)
         if arith == ARITH_Q15:
             cfg.num_biquad_nodes = len(biquad_nodes)
             for k, stages in enumerate(biquad_nodes):
@@ -649,19 +661,27 @@ class Chain(_Instance):
     def set_taps(self, tapset, coeffs_i, coeffs_q):
         tdt = np.float32 if self.arith == ARITH_F32 else np.int16
         ci, cq = np.ascontiguousarray(coeffs_i, tdt), np.ascontiguousarray(coeffs_q, tdt)
+        if ci.size != self.ntaps or cq.size != self.ntaps:
+            raise ValueError("set_taps: %d / %d taps given, the chain was created with %d (numTaps is fixed at creation, as in CMSIS)" % (ci.size, cq.size, self.ntaps))
         _ck(self.ctx.lib.msdr_chain_set_taps(self.h, C.c_uint32(tapset), _hp(ci), _hp(cq)))
 
     def set_osc(self, osc_i, osc_q):
         tdt = np.float32 if self.arith == ARITH_F32 else np.int16
         oi, oq = np.ascontiguousarray(osc_i, tdt), np.ascontiguousarray(osc_q, tdt)
+        if self.osc_len and (oi.size != self.osc_len or oq.size != self.osc_len):
+            raise ValueError("set_osc: tables of %d / %d entries, the chain's have %d" % (oi.size, oq.size, self.osc_len))
         _ck(self.ctx.lib.msdr_chain_set_osc(self.h, _hp(oi), _hp(oq)))
 
     def set_node_coefficients(self, node, stage, coef):
         c = np.ascontiguousarray(coef, np.int32)
+        if c.size != 5:
+            raise ValueError("set_node_coefficients: one stage = 5 words (b0, b1, b2, a1, a2), %d given" % c.size)
         _ck(self.ctx.lib.msdr_chain_set_node_coefficients(self.h, C.c_uint32(node), C.c_uint32(stage), _hp(c)))
 
     def set_biquad_coeffs(self, coeffs):
         c = np.ascontiguousarray(coeffs, np.float32).reshape(-1)
+        if self.stages and c.size != 5 * self.stages:
+            raise ValueError("set_biquad_coeffs: %d values given, the chain's cascade has %d stages x 5" % (c.size, self.stages))
         _ck(self.ctx.lib.msdr_chain_set_biquad_coeffs(self.h, _hp(c)))
 
     def info(self):

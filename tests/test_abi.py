@@ -173,3 +173,26 @@ def test_cascade_info_routes_the_reference_cascade_to_the_parallel_solver(orc):
     assert msdr.biquad_cascade_info(rows([(HP, 300.0, 0.707)] * 2))[0] > 1e4
     assert msdr.biquad_cascade_info(rows([(NT, 300.0, 20.0), (LP, 5000.0, 0.7)]))[2]
     assert msdr.biquad_cascade_info(np.zeros((0, 5), np.float32)) == (1.0, 0.0, False)
+
+
+def test_python_setters_refuse_arrays_of_the_wrong_length():
+    """the C setters copy num_taps / osc_len / 5 x stages elements from the caller's pointer; the ctypes wrappers must not hand
+    them a shorter numpy array (a host out-of-bounds read that becomes the live filter).  Checked on the class methods without a device."""
+    import inspect
+    sys.path.insert(0, os.path.join(ROOT, "minimal-sdr_amd", "python"))
+    import msdr
+    for cls, names in ((msdr.Chain, ("set_taps", "set_osc", "set_biquad_coeffs", "set_node_coefficients")),
+                       (msdr.FirQ15, ("set_coeffs",)), (msdr.FirF32, ("set_coeffs",)), (msdr.BiquadDf1F32, ("set_coeffs",))):
+        for n in names:
+            assert "raise ValueError" in inspect.getsource(getattr(cls, n)), (cls.__name__, n)
+    # and one of them end to end on an object that never reaches the library
+    c = msdr.Chain.__new__(msdr.Chain)
+    c.arith, c.ntaps, c.osc_len, c.stages = msdr.ARITH_F32, 102, 128, 2
+    import numpy as np
+    import pytest
+    with pytest.raises(ValueError):
+        c.set_taps(0, np.zeros(50, np.float32), np.zeros(102, np.float32))
+    with pytest.raises(ValueError):
+        c.set_osc(np.zeros(64, np.float32), np.zeros(64, np.float32))
+    with pytest.raises(ValueError):
+        c.set_biquad_coeffs(np.zeros(5, np.float32))

@@ -382,7 +382,12 @@ typedef struct {
                                       *   kappa > 30 (20 from three sections on), kappa x fp32_noise > 2e-5 or fp32_noise > 2e-6, when a host-side emulation of
                                       *   the block-parallel evaluation is more than 1.5 x fp32_noise + 2e-7 from float64 on the host's test signal, and for three or four sections behind the
                                       *   general kernel.  Where the cascade removes most of its input (stacked high-passes), 1e-5 and 1e-6 are referred to the
-                                      *   level of the cascade's input.  With the reference's filters and all BASELINE configurations: 5-6e-7. */
+                                      *   level of the cascade's input.  With the reference's filters and all BASELINE configurations: 5-6e-7.
+                                      *   Round 5, frozen: the second clause is held on EVERY output row, excused or not -- the library is never further from the
+                                      *   exact result than twice the CMSIS order's own distance + fp32_noise + 1e-6 of the cascade's input level (measured: at most
+                                      *   0.47 of that bound).  That is what gives the gate teeth below 1e-5: builds with the taps cut to 16 bits (4e-6), the lo
+                                      *   tap pieces dropped, or time segments without warm-up fail it (tests/test_gpu_f32_teeth.py).  The error model behind each
+                                      *   term is DESIGN.md 5; a further term needs an argument from the reference's arithmetic, not a fuzz finding. */
     uint32_t num_biquad_nodes;       /* Q15: 0..2 AudioFilterBiquad nodes in series (biquad1_dac, biquad2_dac) */
     uint32_t node_stages[2];         /* Q15: stages used in each node (1..4) */
     const int32_t *node_coefs[2];    /* Q15: host, 5*node_stages[k] ints as given to setCoefficients */

@@ -2605,10 +2605,16 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
                                 T.frags.resize(base + 1024);                          // hi piece [64 lanes][8], then lo piece
                                 for (int l = 0; l < 64; l++)
                                     for (int jj = 0; jj < 8; jj++) {
-                                        const double val = M[o][(size_t)(2 * (16 * j + 8 * (l >> 5) + jj) + src) * 32 + (l & 31)] * scale;
+                                        double val = M[o][(size_t)(2 * (16 * j + 8 * (l >> 5) + jj) + src) * 32 + (l & 31)] * scale;
+#if defined(MSDR_MUTATE) && MSDR_MUTATE == 2       /* `make mutants`, never the product: the taps rounded to 16 significant bits */
+                                        if (val != 0.0) { int e_; const double f_ = std::frexp(val, &e_); val = std::ldexp(std::nearbyint(std::ldexp(f_, 16)), e_ - 16); }
+#endif
                                         const _Float16 vh = (_Float16)val;
                                         T.frags[base + l * 8 + jj] = vh;
                                         T.frags[base + 512 + l * 8 + jj] = (_Float16)(val - (double)vh);
+#if defined(MSDR_MUTATE) && MSDR_MUTATE == 1       /* `make mutants`, never the product: the lo pieces of the tap fragments dropped (the xh x Bl product is gone) */
+                                        T.frags[base + 512 + l * 8 + jj] = (_Float16)0.0f;
+#endif
                                     }
                             }
                         }
@@ -3119,6 +3125,9 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             else if (c->pole_radius > 0) w = (long long)std::ceil(std::log(use_mfw ? 1e-8 : 1e-10) / std::log(c->pole_radius)) + 64 * c->nstages;
         }
         warm_tiles = (w + kTile - 1) / kTile;
+#if defined(MSDR_MUTATE) && MSDR_MUTATE == 3           /* `make mutants`, never the product: time segments start their cascade from zero state, no re-convergence */
+        warm_tiles = 0;
+#endif
         if (warm_tiles > 64 * (use_mfw ? 4 : 1)) can_split = false;
     }
     // segment count for `nch` channels that are launched together

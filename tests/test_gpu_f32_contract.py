@@ -90,6 +90,19 @@ def _judge(ctx, orc, cs, tag, stats):
         e_go = rel_rms(got[c], want)
         stats["checks"] += 1
         if e_go < 1e-5:
+            # The gate's TEETH (round 5): 1e-5 of the oracle is the north-star's tolerance, but the library sits at 5e-7 -- a kernel degraded
+            # twentyfold (taps at 16 bits: 4e-6) would pass it.  So every case is ALSO held against float64 with the contract's second clause,
+            # whether or not the first one needed excusing: never more than twice the CMSIS order's own distance from the exact result
+            # (+ the cascade's fp32_noise + 1e-6 of the cascade's input level).  tests/test_gpu_f32_teeth.py shows mutated builds fail here.
+            t = truth64(cs["x"][c], int(cs["modes"][c]), cs["hi"], cs["hq"], cs["oi"], cs["oq"], cs["bq"])
+            e_gpu, e_orc = rel_rms(got[c], t), rel_rms(want, t)
+            noise = msdr.biquad_cascade_info(cs["bq"])[1]
+            lvl = 1.0
+            if e_gpu > 2 * e_orc + noise + 1e-6:
+                pre = orc.chain_f32(cs["x"][c], cs["modes"][c], cs["hi"], cs["hq"], cs["oi"], cs["oq"], None)
+                lvl = max(1.0, float(np.sqrt((pre.astype(np.float64) ** 2).mean() / max((want.astype(np.float64) ** 2).mean(), 1e-300))))
+            stats["tight_worst"] = max(stats.get("tight_worst", 0.0), e_gpu / (2 * e_orc + noise + 1e-6 * lvl))
+            assert e_gpu <= 2 * e_orc + noise + 1e-6 * lvl, (tag, int(c), kernel, "TIGHT clause: gpu-oracle %.2e gpu-f64 %.2e oracle-f64 %.2e level %.1f fp32_noise %.2e" % (e_go, e_gpu, e_orc, lvl, noise))
             continue
         stats["over"] += 1
         # a cascade that removes most of its input turns the 5e-7 agreement in front of it into a larger RELATIVE error of what is left (any
@@ -120,8 +133,8 @@ def test_fp32_contract_on_the_fuzzers_cases(ctx, orc):
     for seed, cases in ((2026, list(range(1, 151)) + [39938]), (88, range(1, 26)), (911, range(1, 26)), (4106, [46411, 34917]), (4206, [9392, 12427, 16133, 19455])):
         for case in cases:
             _judge(ctx, orc, _case(orc, seed, case), (seed, case), stats)
-    print("fp32 contract: %d channel checks, %d beyond 1e-5 of the fp32 oracle: %d within 1e-5 of the cascade's input level, the others judged against float64 (worst e_gpu / e_orc %.2f)"
-          % (stats["checks"], stats["over"], stats["attenuating"], stats["worst"]))
+    print("fp32 contract: %d channel checks, %d beyond 1e-5 of the fp32 oracle: %d within 1e-5 of the cascade's input level, the others judged against float64 (worst e_gpu / e_orc %.2f); "
+          "every case against float64: worst e_gpu / (2 e_orc + fp32_noise + 1e-6 level) = %.2f" % (stats["checks"], stats["over"], stats["attenuating"], stats["worst"], stats.get("tight_worst", 0.0)))
     assert stats["checks"] >= 200
     assert stats["over"] >= 1, "no case exercised the float64 criterion: the seeds no longer reproduce the fuzzers' cases"
 

@@ -2284,7 +2284,8 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
         // no short period: every AudioEffectFreqConv table still repeats with the block (128 entries, freq_conv.cpp:67-103) -- the
         // matrix-core kernel then stages the two mixer products as full-rate streams and runs both FIRs over every sample
         // (up to 247 taps: beyond that the window does not fit next to the fragments; chain_kernel<ArithF32> takes those)
-        c->mf_fr = oc.empty() && cfg->mixer == MSDR_MIXER_NCO && cfg->osc_len > 0 && (128 % cfg->osc_len) == 0 && c->ntaps < 248;
+        c->mf_fr = oc.empty() && cfg->mixer == MSDR_MIXER_NCO && cfg->osc_len > 0 && (128 % cfg->osc_len) == 0 &&
+                   c->ntaps < (getenv("MSDR_FR_MAX_TAPS") ? (uint32_t)atoi(getenv("MSDR_FR_MAX_TAPS")) : 100000u);      // (round 5: whether the fragments fit LDS beside a wave's windows is decided where the tables are built; the variable re-creates round 4's limit of 248 for A/B runs)
         if (c->mf_fr) c->mf_P = 1;                             // one table per (tap set, flavour): the oscillator is not in it
         if (oc.size() > 4) oc.clear();                         // no VALU fold tables beyond period 4
         if (!oc.empty()) {
@@ -2589,6 +2590,9 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
                     T.h.am = (v == 2); T.h.numfold = numfold; T.h.post = (float)((double)c->in_scale / scale);
                     T.h.iirfold = fold_iir || fold_am; T.h.ipost = (float)(scale / (double)c->in_scale);
                     int ns = 0;
+                    // full rate, envelope table, one low-pass for both streams: M[1] over the Q positions IS M[0] over the I positions -- one set of
+                    // fragments serves both accumulators (half the LDS: 512 taps fit where two sets do not)
+                    const bool share = fr && v == 2 && memcmp(hi, hq, (size_t)N * sizeof(float)) == 0;
                     for (int o = 0; o < (v == 2 ? 2 : 1); o++)
                         for (int src = 0; src < 2; src++) {
                             int jlo = J, jhi = -1;                                   // chunks with any non-zero entry: one contiguous run
@@ -2600,6 +2604,8 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
                             }
                             T.h.run[o][src].j0 = (jhi >= 0) ? jlo : 0;
                             T.h.run[o][src].cnt = (jhi >= 0) ? jhi - jlo + 1 : 0;
+                            if (o == 1 && src == 0) T.h.acc1_base = share ? 0 : ns;      // (accumulator 1's fragments start behind accumulator 0's two runs)
+                            if (share && o == 1) continue;                             // same chunks, same values as run[0][0]: stored once
                             for (int j = jlo; j <= jhi; j++, ns++) {
                                 const size_t base = T.frags.size();
                                 T.frags.resize(base + 1024);                          // hi piece [64 lanes][8], then lo piece

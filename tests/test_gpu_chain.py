@@ -423,8 +423,12 @@ def test_chain_f32_am_with_non_fs4_nco(ctx, orc, engine):
 @pytest.mark.parametrize("ntaps", [248, 257, 513])
 @pytest.mark.parametrize("mode", [orclib.LSB, orclib.USB, orclib.AM])
 def test_chain_f32_long_fir_behind_a_general_table_vs_oracle(ctx, orc, ntaps, mode):
-    """More than 247 taps behind an oscillator table that is NOT short-periodic: the full-rate matrix-core layout holds up to 247 taps,
-    beyond that the as-written kernel runs (chain_kernel<ArithF32>; round 2's overlap-save FFT kernel for this corner is gone)."""
+    """More than 247 taps behind an oscillator table that is NOT short-periodic (every AudioEffectFreqConv table repeats with the 128-sample
+    block whatever is in it, freq_conv.cpp:67-103).  Round 5: the full-rate matrix-core layout takes every tap count whose fragments fit LDS
+    beside a wave's windows (to ~400 taps; round 4 stopped at 247 and fell to the vector ALU: 256 taps 0.07 -> 0.17 of the roof on c4's
+    shape), and an envelope table whose two streams meet ONE low-pass (hI == hQ, the reference's AM case: this test's AM rows) stores its
+    fragments once.  At 513 taps the SSB tables of the same tap set (every chain carries all three flavours: a retune may ask for any) do not
+    fit: chain_kernel<ArithF32> answers (the as-written evaluation)."""
     rng = np.random.default_rng(ntaps * 3 + mode)
     if mode == orclib.AM:
         hi = (np.sinc(2 * 2800 / 24000 * (np.arange(ntaps) - (ntaps - 1) / 2)) * np.kaiser(ntaps, 7.0)).astype(np.float32)
@@ -439,7 +443,9 @@ def test_chain_f32_long_fir_behind_a_general_table_vs_oracle(ctx, orc, ntaps, mo
     for block in (None, 4999, 128):
         chain.reset()
         got = run_chain(ctx, chain, x, np.float32, block)
-        assert chain.info()["kernel"] == "chain_kernel<ArithF32>", chain.info()
+        if block != 128:
+            want_kernel = "chain_kernel<ArithF32>" if ntaps > 500 else "chain_mfw_kernel<2> full-rate NCO streams"
+            assert chain.info()["kernel"] == want_kernel, chain.info()
         for c in range(3):
             want = orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq)
             assert rel_rms(got[c], want) < TOL, (block, c, rel_rms(got[c], want))

@@ -725,11 +725,16 @@ def attach_traffic(out, tag, args):
     WRITE_SIZE x 1024, corrected as MI355X_MICROARCH.md prescribes).  It is attached only when the profile was taken on the kernel
     THIS run launched (names compared) and the run is the named configuration: any shape override, experiment switch or MSDR_*
     kernel-selection variable leaves `traffic` null."""
-    if (args.samples or args.channels or args.taps or args.stages >= 0 or args.no_mfma or args.no_fold or getattr(args, "out_i16", False)
-            or args.time_segments or args.osc_period != 4 or any(k.startswith("MSDR_") and k not in ("MSDR_LIB", "MSDR_BENCH_REHEARSAL", "MSDR_BENCH_NO_POWER") for k in os.environ)):
+    named = getattr(args, "named_record", None)          # a sub-record of the default run whose shape override IS its definition (fir512, c3_b128, c3_i16 ...): its own tag
+    if named:
+        tag = named
+    elif (args.samples or args.channels or args.taps or args.stages >= 0 or args.no_mfma or args.no_fold or getattr(args, "out_i16", False)
+            or args.time_segments or args.osc_period != 4):
+        return
+    if any(k.startswith("MSDR_") and k not in ("MSDR_LIB", "MSDR_BENCH_REHEARSAL", "MSDR_BENCH_NO_POWER") for k in os.environ):
         return
     ran = str(out["config"].get("kernel", "")).split("<")[0].split(" ")[0]
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         prof = os.path.join(ROOT, "profiles", rnd, "%s_rocprof_summary.txt" % tag)
         if not os.path.exists(prof):
             continue
@@ -1311,6 +1316,14 @@ def main():
             also["fir"] = bench_fir_stage(args, torch, msdr, ctx, dev, rank, world, dist, do_cpu)
             if also["fir"] is not None:                  # (records exist on rank 0 only)
                 also["fir"]["warmup_steps_run"] = args.warmup_steps_run
+        if args.arith == "f32":
+            # the same stage at C5's 512 taps (past the taps-in-registers layout's ~290: fir_f32mf_kernel, taps in LDS)
+            keep_taps = args.taps
+            args.taps, args.named_record = 512, "fir_f32_512"
+            also["fir512"] = bench_fir_stage(args, torch, msdr, ctx, dev, rank, world, dist, do_cpu)
+            args.taps, args.named_record = keep_taps, None
+            if also["fir512"] is not None:
+                also["fir512"]["warmup_steps_run"] = args.warmup_steps_run
         for name in ("c2", "c4", "c5"):
             also[name] = bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, False, False)   # parity windows, no timed CPU leg
             if also[name] is not None:
@@ -1322,9 +1335,9 @@ def main():
             also["q15_c3"] = bench_chain(args, "c3", torch, msdr, ctx, dev, rank, world, dist, False, False)
             args.arith = "f32"
             # the headline with int16 audio out (the play queue's type): the same arithmetic, 4 B per sample through HBM instead of 6
-            args.out_i16 = True
+            args.out_i16, args.named_record = True, "c3_i16"
             also["c3_i16"] = bench_chain(args, "c3", torch, msdr, ctx, dev, rank, world, dist, False, False)
-            args.out_i16 = False
+            args.out_i16, args.named_record = False, None
             if also["c3_i16"] is not None:
                 also["c3_i16"]["warmup_steps_run"] = args.warmup_steps_run
             if also["q15_c3"] is not None:
@@ -1334,8 +1347,9 @@ def main():
             keep_steps, keep_samples = args.steps, args.samples
             args.steps, args.samples = max(args.steps, 200), 128
             for name, wl_name, q in (("c3_b128", "c3", False), ("c4_b128", "c4", False), ("q15_c3_b128", "c3", True)):
-                args.arith = "q15" if q else "f32"
+                args.arith, args.named_record = ("q15" if q else "f32"), name
                 also[name] = bench_chain(args, wl_name, torch, msdr, ctx, dev, rank, world, dist, False, False)
+                args.named_record = None
                 if also[name] is not None:
                     also[name]["warmup_steps_run"] = args.warmup_steps_run
                     also[name]["config"]["steps_timed"] = args.steps

@@ -427,7 +427,8 @@ def test_biquad_df1_f32_cmsis_order_long_stream_of_few_channels(ctx, orc, ch, sp
         assert np.abs(got[c, tail] - want[tail]).max() < 1e-4 * np.abs(want[tail]).max() + 1e-6, (spec, c)
 
 
-@pytest.mark.parametrize("ntaps", [16, 17, 33, 48, 49, 64, 65, 97, 113, 128, 129, 161, 193, 225, 242, 257, 289, 290, 321])
+@pytest.mark.parametrize("ntaps", [16, 17, 33, 48, 49, 64, 65, 97, 113, 128, 129, 161, 193, 225, 242, 257, 289, 290, 321,
+                                   352, 385, 417, 449, 481, 512, 513, 545, 577])      # (round 5: 321 - 577, C5's 512 among them: fir_f32mf_kernel, the same bound)
 def test_fir_f32_taps_in_registers_every_step_count(ctx, orc, ntaps):
     """msdr_fir_f32tr.hiph: one instantiation per number of 32-sample k-steps (2 .. 10: 16 .. 289 taps; longer filters stay on
     msdr_fir_f32mf.hiph).  Tap counts on both sides of every boundary, with and without the all-zero first step of the second

@@ -1,3 +1,6 @@
+// tools/probes/fir_f32tq_abl_kernel.hip -- the ABLATION copy of minimal-sdr_amd/csrc/msdr_fir_f32tq.hiph (round 5: the product kernel no
+// longer carries these switches; this file is included by tools/probes/fir_tq_bench.hip only and must follow the product kernel by hand).
+// ---- the product header's text from here on, with `ABL` ----
 // msdr_fir_f32tq.hiph -- arm_fir_f32 (prototype src/CMSIS_5/arm_math.h:1182-1186; CMSIS-DSP 1.5.x semantics
 // y[n] = sum_k pCoeffs[k] x[n-(N-1)+k]): the taps-in-registers kernel of msdr_fir_f32tr.hiph with the TILES DEALT
 // FROM A QUEUE IN ADDRESS ORDER instead of one long stream per wave (gfx950, round 3).
@@ -23,39 +26,17 @@
 // bounds checks ("cold").  The two counter sets alternate between launches: a launch zeroes the set the next one will use.
 // Arithmetic, tap tables, window layout and parking are msdr_fir_f32tr.hiph's.  Algorithmic bytes: 4 in + 4 out per sample.
 #pragma once
-#include "msdr_fir_f32tr.hiph"
+#include "msdr_fir_f32tq.hiph"      // TqParams, the load / store policy, the layout
+#define MSDR_TQ_ABL_COPY 1
 
 namespace msdr {
 
-// load / store policy of the streamed tiles (A/B by tools/probes/fir_tq_bench.hip, profiles/r03/fir_tq_ablation.txt)
-#ifndef MSDR_TQ_LOAD
-#define MSDR_TQ_LOAD(p_) __builtin_nontemporal_load(p_)
-#endif
-#ifndef MSDR_TQ_STORE
-#define MSDR_TQ_STORE(v_, p_) __builtin_nontemporal_store(v_, p_)
-#endif
-
-constexpr int kTqCtrStride = 16;               // unsigned words between the counters of two fronts (64 bytes)
-constexpr int kTqMaxFronts = 64;
-constexpr unsigned kTqNone = 0xFFFFFFFFu;
-
-struct TqParams {
-    const float *x; float *y; const float *hist; const char *tab;
-    long long n;                               // samples per channel row
-    int channels, hist_len;
-    unsigned tpr;                              // tiles per row
-    int tpr_shift;                             // log2(tpr) when tpr is a power of two, else -1
-    unsigned total;                            // channels x tpr
-    unsigned fronts, per_front;                // front f covers tiles [f per_front, min((f + 1) per_front, total))
-    unsigned *ctr, *ctr_next;                  // this launch's counters (zero on entry); the next launch's, zeroed here
-    int all_aligned;                           // every row of x and y starts on a 16-byte boundary
-    int run_shift;                             // a draw hands out a RUN of 2^run_shift consecutive tiles (round 4: the second .. last tile of a run take their halo from the registers of the tile before)
-};
-
-// (The ablation switches rounds 3 - 4 measured this kernel with -- no matrix instructions, no global traffic, round-robin tiles, the fast-FIR
-//  instruction mix -- live in tools/probes/fir_f32tq_abl_kernel.hip, a copy for tools/probes/fir_tq_bench.hip; the product carries none.)
-template <int NS, bool SKIP1>
-__global__ __launch_bounds__(256, 2) void fir_f32tq_kernel(const TqParams p)
+// ABL (diagnostic instantiations of tools/probes/fir_tq_bench.hip only; the library builds ABL = 0): 1 = no matrix instructions,
+// 2 = no global loads / stores in the steady state, 4 = tiles assigned round-robin inside the front instead of drawn,
+// 8 = 30 of the 36 product triples of a 9-step tile (what a 2 x 2 block-Toeplitz "fast FIR" split would issue; results meaningless),
+// 16 = the side work such a split adds: half as many conversions again (the pre-added third stream) and a third fragment pair per two k-steps
+template <int NS, bool SKIP1, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void fir_f32tq_abl_kernel(const TqParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int H = 32 * (NS - 1);
@@ -132,7 +113,13 @@ __global__ __launch_bounds__(256, 2) void fir_f32tq_kernel(const TqParams p)
                      : "=s"(g) : "v"(gp), "n"(decltype(younger_tag)::value) : "memory");
         return g < nruns ? fbase + (g << p.run_shift) : kTqNone;
     };
-    auto draw_sync = [&]() -> unsigned { unsigned gp; draw_issue(gp, 1u); return draw_take(gp, std::integral_constant<int, 0>{}); };
+    // (ABL & 4: round-robin instead -- wave r of the front's waves takes tiles r, r + R, r + 2 R ...)
+    const unsigned rr_step = ((gridDim.x - front + p.fronts - 1) / p.fronts) * 4u;
+    unsigned rr_next = (blockIdx.x / p.fronts) * 4u + (unsigned)wave;
+    auto draw_sync = [&]() -> unsigned {
+        if constexpr (ABL & 4) { const unsigned g = rr_next; rr_next += rr_step; return g < fcount ? fbase + g : kTqNone; }
+        unsigned gp; draw_issue(gp, 1u); return draw_take(gp, std::integral_constant<int, 0>{});
+    };
     auto next_sync = [&](unsigned idx) -> unsigned { return run_more(idx) ? idx + 1u : draw_sync(); };      // the tile behind idx in this wave's sequence
     // tile idx -> (row offset in samples, first sample inside the row, "full": complete and aligned -- its outputs may leave as four
     // 1 KB stores --, "hot": full and its halo inside the row -- its window may be streamed)
@@ -219,10 +206,17 @@ __global__ __launch_bounds__(256, 2) void fir_f32tq_kernel(const TqParams p)
 #pragma unroll
             for (int F = 0; F < 2; F++) {
                 if (SKIP1 && F == 1 && s == 0) continue;
+                if ((ABL & 8) && j == 1 && F == 1 && s < 6) continue;
+                if constexpr (ABL & 1) { acc[j][F] += (f32x4){(float)xl[0], (float)xh[1], (float)th[F][s][0], (float)tl[F][s][1]}; continue; }
                 acc[j][F] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th[F][s], xl, acc[j][F], 0, 0, 0);
                 acc[j][F] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th[F][s], xh, acc[j][F], 0, 0, 0);
                 acc[j][F] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl[F][s], xh, acc[j][F], 0, 0, 0);
             }
+        }
+        if constexpr ((ABL & 16) != 0 && (sx & 1) == 0 && sx < NS) {       // a third stream's fragments: read and folded in so that they stay
+            constexpr int off2 = ((sx + 2) >> 1) * kTrBlk;
+            const f16x8 eh = *reinterpret_cast<const f16x8 *>(w + xoff + off2), el = *reinterpret_cast<const f16x8 *>(w + xoff + AS + off2);
+            acc[0][0][0] += (float)eh[0] + (float)el[0];
         }
         xh = nh; xl = nl;
     };
@@ -300,26 +294,35 @@ __global__ __launch_bounds__(256, 2) void fir_f32tq_kernel(const TqParams p)
             // bytes in flight cost bandwidth on this part, profiles/r03/stream_order.md.)
             auto side = [&](auto i_tag) {
                 constexpr int i = decltype(i_tag)::value;
-                if constexpr (i == 0) { draw_issue(gp, cont ? 0u : 1u); pv[0] = park_read(0); pv[1] = park_read(1); }
-                if constexpr (i == 1) { store_full(zo, 0, pv[0]); store_full(zo, 1, pv[1]); pv[2] = park_read(2); pv[3] = park_read(3); }
-                if constexpr (i == 2) { store_full(zo, 2, pv[2]); store_full(zo, 3, pv[3]); }
+                if constexpr (i == 0) { if constexpr (!(ABL & 4)) draw_issue(gp, cont ? 0u : 1u); pv[0] = park_read(0); pv[1] = park_read(1); }
+                if constexpr (i == 1) { if constexpr (!(ABL & 2)) { store_full(zo, 0, pv[0]); store_full(zo, 1, pv[1]); } pv[2] = park_read(2); pv[3] = park_read(3); }
+                if constexpr (i == 2) { if constexpr (!(ABL & 2)) { store_full(zo, 2, pv[2]); store_full(zo, 3, pv[3]); } else { pre[0] += pv[0] + pv[1] + pv[2] + pv[3]; } }
                 if constexpr (i == 3) { scale_next(); }
                 if constexpr (i == 4) { convert(wn, 0); convert(wn, 1); }
                 if constexpr (i == 5) {
 #pragma unroll
                     for (int j = 2; j < NLD; j++) convert(wn, j);
+                    if constexpr (ABL & 16) {          // the pre-added stream: (NLD + 1) / 2 more chunks converted (x0 + x1, its own split), written over the parked tile
+#pragma unroll
+                        for (int j = 0; j < (NLD + 1) / 2; j++) tr_write4_at(park + (lane & 15) * 16 + 256 * j, 2048, pre[2 * j] + pre[(2 * j + 1) % NLD], fm_pow2(knew));
+                    }
                 }
                 if constexpr (i == 6) {
-                    if constexpr (kReuse) {
-                        if (creuse) {
-                            pre[0] = pre[NLD - 1];
+                    if constexpr (!(ABL & 2)) {
+                        if constexpr (kReuse) {
+                            if (creuse) {
+                                pre[0] = pre[NLD - 1];
 #pragma unroll
-                            for (int j = 1; j < NLD; j++) fetch_chunk(frow, ft0, j);
+                                for (int j = 1; j < NLD; j++) fetch_chunk(frow, ft0, j);
+                            } else fetch_hot(frow, ft0);
                         } else fetch_hot(frow, ft0);
-                    } else fetch_hot(frow, ft0);
-                    // younger than the draw on every path: Z's four stores, C's loads (a partial last load is conditional, the halo load is skipped inside a run: not counted)
-                    didx = draw_take(gp, std::integral_constant<int, NLD + 4 - (kWholeLoads ? 0 : 1) - (kReuse ? 1 : 0)>{});
-                    if (cont) didx = cidx + 1u;
+                    }
+                    if constexpr (ABL & 4) { didx = rr_next < fcount ? fbase + rr_next : kTqNone; rr_next += rr_step; }
+                    else {
+                        // younger than the draw on every path: Z's four stores, C's loads (a partial last load is conditional, the halo load is skipped inside a run: not counted)
+                        didx = draw_take(gp, std::integral_constant<int, (ABL & 2) ? 0 : NLD + 4 - (kWholeLoads ? 0 : 1) - (kReuse ? 1 : 0)>{});
+                        if (cont) didx = cidx + 1u;
+                    }
                     if (didx != kTqNone) geo(didx, drow, dt0, dfull, dhot);
                 }
             };
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void fir_f32tq_kernel(const TqParams p)
         unsigned char *wn = win0 + (cur ^ 1) * WB;
         unsigned gp = 0u;
         const bool cont_cold = run_more(cidx);
-        draw_issue(gp, cont_cold ? 0u : 1u);        // (unconditional, as its take below: once the queue is dry a draw comes back empty)
+        if constexpr (!(ABL & 4)) draw_issue(gp, cont_cold ? 0u : 1u);        // (unconditional, as its take below: once the queue is dry a draw comes back empty)
         if (zvalid) {
             if (zfull) {
                 float *zo = p.y + zrow + zt0;
@@ -365,8 +368,7 @@ __global__ __launch_bounds__(256, 2) void fir_f32tq_kernel(const TqParams p)
         park_write();
         zvalid = true; zfull = afull; zrow = arow; zt0 = at0;
         unsigned didx;
-        didx = draw_take(gp, std::integral_constant<int, 0>{});
-        if (cont_cold) didx = cidx + 1u;
+        if constexpr (ABL & 4) didx = draw_sync(); else { didx = draw_take(gp, std::integral_constant<int, 0>{}); if (cont_cold) didx = cidx + 1u; }
         if (bidx != kTqNone) {
             if (have_pre) {
                 scale_next();

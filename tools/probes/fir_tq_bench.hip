@@ -13,6 +13,7 @@
 #include <vector>
 #include "msdr_shared.h"
 #include "msdr_fir_f32tq.hiph"
+#include "fir_f32tq_abl_kernel.hip"      // the kernel with its ablation switches: a copy kept beside this probe (the product header has none)
 
 using namespace msdr;
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -31,7 +32,7 @@ static double run(const char *name, TqParams q, unsigned grid, size_t lds, unsig
 {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fir_f32tq_kernel<9, false, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fir_f32tq_abl_kernel<9, false, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     std::vector<float> t;
     int flip = 0;
     CHECK(hipMemset(d_ctr, 0, 2 * kTqMaxFronts * kTqCtrStride * 4));
@@ -40,7 +41,7 @@ static double run(const char *name, TqParams q, unsigned grid, size_t lds, unsig
         q.ctr = d_ctr + (size_t)flip * kTqMaxFronts * kTqCtrStride; q.ctr_next = d_ctr + (size_t)(flip ^ 1) * kTqMaxFronts * kTqCtrStride;
         flip ^= 1;
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL((fir_f32tq_kernel<9, false, ABL>), dim3(grid), dim3(256), lds, 0, q);
+        hipLaunchKernelGGL((fir_f32tq_abl_kernel<9, false, ABL>), dim3(grid), dim3(256), lds, 0, q);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));

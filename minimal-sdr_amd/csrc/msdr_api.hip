@@ -902,7 +902,7 @@ extern "C" int msdr_fir_q15_process(msdr_fir_q15 *S, const q15_t *d_src, q15_t *
     while (nw > 1 && qm_lds_bytes(S->qm_halo, S->qm_bsteps, nw) > 80 * 1024) nw >>= 1;
     q.mf_nw = nw; q.nseg = (int)qseg; q.seg_len = qseg_len; q.fold_period = 0; q.fold_rot = (int)S->channels; q.mf_waves = 0;
     const unsigned grid = (unsigned)(((long long)S->channels * qseg + nw - 1) / nw);
-    { KernelTimer kt(S->ctx); hipLaunchKernelGGL(chain_q15mf_kernel<3>, dim3(grid), dim3(nw * 64), qm_lds_bytes(S->qm_halo, S->qm_bsteps, nw), S->ctx->stream, q); }
+    { KernelTimer kt(S->ctx); (void)launch_chain_q15mf(S->ctx->stream, 3, false, grid, (unsigned)nw * 64, qm_lds_bytes(S->qm_halo, S->qm_bsteps, nw), q); }
     if (int rc = launch_check("chain_q15mf_kernel<3>")) return rc;
     hipLaunchKernelGGL((history_kernel<int16_t>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
                        d_src, (const int16_t *)S->d_hist[S->cur], S->d_hist[S->cur ^ 1], (long long)blockSize, (int)S->hist_len, (int)S->channels);
@@ -1050,17 +1050,8 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
         { const int cap = S->tq_run_shift_cap;
           while (q.run_shift < cap && (q.tpr >> (q.run_shift + 1)) >= 1 && (S->tq_run_forced || (long long)q.total >= (long long)grid * 4 * 64 * (2LL << q.run_shift))) q.run_shift++; }
         const size_t lds = 4 * tr_wave_bytes(S->tr_ns);
-#define MSDR_TQ_LAUNCH(NS_) case NS_: \
-            if (S->tr_skip1) hipLaunchKernelGGL((fir_f32tq_kernel<NS_, true>), dim3(grid), dim3(256), lds, S->ctx->stream, q); \
-            else hipLaunchKernelGGL((fir_f32tq_kernel<NS_, false>), dim3(grid), dim3(256), lds, S->ctx->stream, q); \
-            break;
         { KernelTimer kt(S->ctx);
-        switch (S->tr_ns) {
-            MSDR_TQ_LAUNCH(2) MSDR_TQ_LAUNCH(3) MSDR_TQ_LAUNCH(4) MSDR_TQ_LAUNCH(5) MSDR_TQ_LAUNCH(6)
-            MSDR_TQ_LAUNCH(7) MSDR_TQ_LAUNCH(8) MSDR_TQ_LAUNCH(9) MSDR_TQ_LAUNCH(10)
-            default: return fail(MSDR_STATUS_ARGUMENT_ERROR, "fir_f32tq: step count not built");
-        } }
-#undef MSDR_TQ_LAUNCH
+          if (launch_fir_f32tq(S->ctx->stream, S->tr_ns, S->tr_skip1, grid, lds, q) == hipErrorInvalidValue) return fail(MSDR_STATUS_ARGUMENT_ERROR, "fir_f32tq: step count not built"); }
         if (int rc = launch_check("fir_f32tq_kernel")) return rc;
         S->tq_flip ^= 1; S->last_launch = 1;
         hipLaunchKernelGGL((history_kernel<float>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
@@ -1079,9 +1070,9 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
     while (nw > 1 && ((long long)S->channels * nseg < 256LL * nw || fm_lds_bytes(H, ns, nw) > 160 * 1024)) nw >>= 1;
     const unsigned grid = (unsigned)(((long long)S->channels * nseg + nw - 1) / nw);
     { KernelTimer kt(S->ctx);
-      hipLaunchKernelGGL(fir_f32mf_kernel, dim3(grid), dim3(nw * 64), fm_lds_bytes(H, ns, nw), S->ctx->stream, d_src, d_dst,
-                       (const float *)S->d_hist[S->cur], (const char *)S->d_fm_tab, (long long)blockSize, (int)S->channels, (int)nseg, seg_len,
-                       (int)S->hist_len, H, ns, nw); }
+      (void)launch_fir_f32mf(S->ctx->stream, grid, (unsigned)nw * 64, fm_lds_bytes(H, ns, nw), d_src, d_dst,
+                             (const float *)S->d_hist[S->cur], (const char *)S->d_fm_tab, (long long)blockSize, (int)S->channels, (int)nseg, seg_len,
+                             (int)S->hist_len, H, ns, nw); }
     if (int rc = launch_check("fir_f32mf_kernel")) return rc;
     S->last_launch = 2;
     hipLaunchKernelGGL((history_kernel<float>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
@@ -3287,34 +3278,11 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
                 a.mf_tab = c->d_at_tab; a.mf_stride = c->at_stride; a.mf_nw = c->at_nw; a.fold_rot = (int)entries;
                 const unsigned ag = (unsigned)((entries + c->at_nw - 1) / c->at_nw);
                 const size_t alds = at_lds_bytes(c->at_ns, c->at_nw);
-#define MSDR_AT_LAUNCH(NS_, SS_) hipLaunchKernelGGL((chain_amtr_kernel<NS_, SS_>), dim3(ag), dim3(c->at_nw * 64), alds, c->ctx->stream, a)
-#define MSDR_AT_STAGES(NS_) switch (c->nstages) { case 0: MSDR_AT_LAUNCH(NS_, 0); break; case 1: MSDR_AT_LAUNCH(NS_, 1); break; case 2: MSDR_AT_LAUNCH(NS_, 2); break; \
-                                                   case 3: MSDR_AT_LAUNCH(NS_, 3); break; default: MSDR_AT_LAUNCH(NS_, 4); break; }
-                switch (c->at_ns) {
-                case 2: MSDR_AT_STAGES(2) break;
-                case 3: MSDR_AT_STAGES(3) break;
-                case 4: MSDR_AT_STAGES(4) break;
-                default: MSDR_AT_STAGES(5) break;
-                }
-#undef MSDR_AT_STAGES
-#undef MSDR_AT_LAUNCH
+                (void)launch_chain_amtr(c->ctx->stream, c->at_ns, (int)c->nstages, ag, (unsigned)c->at_nw * 64, alds, a);
                 if (int rc2 = launch_check("chain_amtr_kernel")) return rc2;
                 continue;
             }
-#define MSDR_MFW_LAUNCH(SS, AMF, FO) do { if (c->mf_fr) hipLaunchKernelGGL((chain_mfw_kernel<SS, AMF, FO, true>), dim3(g), dim3(block), lds, c->ctx->stream, q); \
-                                          else hipLaunchKernelGGL((chain_mfw_kernel<SS, AMF, FO, false>), dim3(g), dim3(block), lds, c->ctx->stream, q); } while (0)
-#define MSDR_MFW_PLAIN(SS) do { if (part == 0) MSDR_MFW_LAUNCH(SS, false, false); else MSDR_MFW_LAUNCH(SS, true, false); } while (0)
-#define MSDR_MFW_FOLDS(SS) do { if (!fold) MSDR_MFW_PLAIN(SS); else if (part == 0) MSDR_MFW_LAUNCH(SS, false, true); else MSDR_MFW_LAUNCH(SS, true, true); } while (0)
-            switch (c->nstages) {
-            case 0: MSDR_MFW_PLAIN(0); break;
-            case 1: MSDR_MFW_FOLDS(1); break;
-            case 2: MSDR_MFW_FOLDS(2); break;
-            case 3: MSDR_MFW_PLAIN(3); break;
-            default: MSDR_MFW_PLAIN(4); break;
-            }
-#undef MSDR_MFW_FOLDS
-#undef MSDR_MFW_PLAIN
-#undef MSDR_MFW_LAUNCH
+            (void)launch_chain_mfw(c->ctx->stream, (int)c->nstages, part == 1, fold, c->mf_fr, g, block, lds, q);
             if (int rc = launch_check("chain_mfw_kernel")) return rc;
         }
         static const char *const names[5] = {"chain_mfw_kernel<0>", "chain_mfw_kernel<1>", "chain_mfw_kernel<2>", "chain_mfw_kernel<3>", "chain_mfw_kernel<4>"};
@@ -3336,10 +3304,11 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         }
 #endif
     }
-    else if (use_fold && c->fold_P == 4) { hipLaunchKernelGGL((chain_fold_kernel<4>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<4>"; }
-    else if (use_fold && c->fold_P == 2) { hipLaunchKernelGGL((chain_fold_kernel<2>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<2>"; }
-    else if (use_fold) { hipLaunchKernelGGL((chain_fold_kernel<1>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p); kname = "chain_fold_kernel<1>"; }
-    else if (f32) hipLaunchKernelGGL((chain_kernel<ArithF32>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p);
+    else if (use_fold) {
+        (void)launch_chain_fold(c->ctx->stream, c->fold_P, grid, lds, p);
+        kname = c->fold_P == 4 ? "chain_fold_kernel<4>" : c->fold_P == 2 ? "chain_fold_kernel<2>" : "chain_fold_kernel<1>";
+    }
+    else if (f32) (void)launch_chain_generic(c->ctx->stream, false, grid, lds, p);
     else if (use_qb) {
         grid = 0;
         for (int part = 0; part < 2; part++) {
@@ -3397,19 +3366,12 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             q.mf_nw = nw; q.nseg = (int)qseg; q.seg_len = qseg_len;
             q.fold_period = (int)c->qm_group_start[gi]; q.fold_rot = (int)cnt; q.mf_waves = (int)(gi / 3);
             grid = (unsigned)((cnt * qseg + nw - 1) / nw);
-#define MSDR_QM_LAUNCH(FL) do { if (c->qm_fr) hipLaunchKernelGGL((chain_q15mf_kernel<FL, true>), dim3(grid), dim3(nw * 64), qlds, c->ctx->stream, q); \
-                                else hipLaunchKernelGGL((chain_q15mf_kernel<FL, false>), dim3(grid), dim3(nw * 64), qlds, c->ctx->stream, q); } while (0)
-            switch ((int)(gi % 3)) {
-            case 0: MSDR_QM_LAUNCH(0); break;
-            case 1: MSDR_QM_LAUNCH(1); break;
-            default: MSDR_QM_LAUNCH(2); break;
-            }
-#undef MSDR_QM_LAUNCH
+            (void)launch_chain_q15mf(c->ctx->stream, (int)(gi % 3), c->qm_fr, grid, (unsigned)nw * 64, qlds, q);
             if (int rc = launch_check("chain_q15mf_kernel")) return rc;
         }
         kname = c->qm_fr ? "chain_q15mf_kernel full-rate NCO streams" : "chain_q15mf_kernel"; block = (unsigned)nw * 64; nseg = qseg;
     }
-    else     hipLaunchKernelGGL((chain_kernel<ArithQ15>), dim3(grid), dim3(kThreads), lds, c->ctx->stream, p);
+    else     (void)launch_chain_generic(c->ctx->stream, true, grid, lds, p);
     if (int rc = launch_check("chain_kernel")) return rc;
     if (e0) { HIP_TRY(hipEventRecord(e1, c->ctx->stream)); c->events.emplace_back(e0, e1); }
 

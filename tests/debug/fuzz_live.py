@@ -53,6 +53,7 @@ def table(rng, q15):
 t_end = time.time() + budget
 case = bad = excused = 0
 ops_seen = {}
+kernels_seen = {}
 while time.time() < t_end:
     case += 1
     if only >= 0:
@@ -137,11 +138,15 @@ while time.time() < t_end:
         for p_ in plan[-2:]:
             ops_seen[p_[0]] = ops_seen.get(p_[0], 0) + 1
         m = int(rng.integers(1, 20)) * B
+        if os.environ.get("FUZZ_BLOCK"):      # round 5: the reference's cadence -- calls the block kernels take (msdr_chain_mfb.hiph / msdr_chain_q15mb.hiph), a longer one now and then
+            m = int(rng.choice([128, 128, 128, 256, 512, 640] if q15 else [32, 64, 128, 128, 128, 256, 512, 640, 100]))
         plan.append(("run", m))
         x = rng.integers(-20000, 20001, (ch, m)).astype(np.int16)
         dx, dy = ctx.to_device(x), ctx.array((ch, m), np.int16 if q15 else np.float32)
         chain.process(dx, dy, m)
         got = dy.download()
+        kname = chain.info()["kernel"].split("<")[0].split(" ")[0]
+        kernels_seen[kname] = kernels_seen.get(kname, 0) + 1
         for c in watch:
             ts = int(tapsets[c])
             if q15:
@@ -165,4 +170,4 @@ while time.time() < t_end:
         if not ok:
             break
     chain.close()
-print("fuzz_live done: %d cases, %d mismatches, %d fp32 checks between 1e-5 and 3e-4 behind random cascades (seed %d); operations exercised: %s" % (case, bad, excused, seed, ops_seen))
+print("fuzz_live done: %d cases, %d mismatches, %d fp32 checks between 1e-5 and 3e-4 behind random cascades (seed %d); operations exercised: %s; main kernels: %s" % (case, bad, excused, seed, ops_seen, kernels_seen))

@@ -1,0 +1,17 @@
+#!/usr/bin/env bash
+# tools/r05_fuzz.sh <part> -- the randomised differential tests of tests/debug/ at the round's final revision (run through gpurun; every
+# fuzzer stays below five minutes so that the call keeps producing output).  Output: gpurun_out/r05f/*.txt, tail lines = the summaries.
+cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+O=gpurun_out/r05f; mkdir -p $O
+run() { name=$1; shift; tools/memguard.sh -m 24 -t 330 python3 tests/debug/$name.py "$@" > $O/${name}_$2.txt 2>&1; echo "$name $*: rc $?"; tail -2 $O/${name}_$2.txt | cut -c1-400; }
+case ${1:-a} in
+  a) run fuzz_kernels 280 5101; run fuzz_live 240 5102; run fuzz_fir_f32 200 5103 ;;
+  b) run fuzz_retune 150 5104; run fuzz_retune_q15 150 5105; run fuzz_f32_truth 240 5106; run fuzz_stage_df1 120 5107 ;;
+  c) run fuzz_pll_anr 120 5108; run fuzz_pll_anr_f32 120 5109; run fuzz_frontend 120 5110; run fuzz_kernels 280 5111 ;;
+  d) run fuzz_kernels 300 5201; run fuzz_live 300 5202; run fuzz_f32_truth 300 5206 ;;     # a second pass with fresh seeds at the round's last revision
+esac
+# round 5: the same live-update fuzzer at the reference's cadence (FUZZ_BLOCK=1: calls of 32 .. 512 samples: the block kernels)
+if [ "${1:-a}" = "e" ]; then
+  export FUZZ_BLOCK=1
+  run fuzz_live 300 5301; run fuzz_live 300 5302
+fi

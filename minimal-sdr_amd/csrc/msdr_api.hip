@@ -2659,6 +2659,9 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
                 if (!rc && iirfold && !iirc.empty()) rc = upload(ctx, iirc, &c->d_mw_iir);
                 c->mfw_ssb_fold = iirfold && c->d_mw_iir; c->mfw_am_fold = amfold && c->d_mw_iir;
                 if (best <= 0) c->mf_ok = false;               // not even one wave's window fits next to the fragments: the VALU kernels run
+                // (full-rate layout: a lone wave per CU waits out every LDS round trip of a 60-step burst on its own -- two waves were 1.4 x the
+                //  vector-ALU kernel at 384 taps, profiles/r05/nco_long_taps.txt; one is not taken)
+                if (fr && c->mfw_nw < 2) c->mf_ok = false;
             }
         }
     }

@@ -2948,15 +2948,21 @@ static int chain_block_tiles(msdr_chain *c, int n_, const std::function<int(uint
     for (int part = 0; part < 2; part++) {
         std::vector<std::pair<size_t, size_t>> groups;          // [begin, end) in `order`
         size_t i = i0;
-        long long tiles_part = 0;
         while (i < order.size() && part_of(order[i]) == part) {
             size_t j = i;
             while (j < order.size() && part_of(order[j]) == part && key_of(order[j]) == key_of(order[i])) j++;
             groups.emplace_back(i, j);
-            tiles_part += (long long)((j - i) + cpt - 1) / cpt;
             i = j;
         }
         i0 = i;
+        // channels placed per tile: all CPT slots -- or fewer while full tiles would leave SIMDs without a wave (a tile is one wave's work: its
+        // staging and stores shrink with the channels in it, its matrix products do not, and an idle SIMD is worth nothing): halve the fill
+        // until the part has a tile for every second SIMD (4096 channels x 128: 512 full tiles on 1024 SIMDs -> 1024 tiles of 4 channels)
+        int fill = cpt;
+        auto tiles_at = [&](int f) { long long t = 0; for (auto &g : groups) t += (long long)((g.second - g.first) + f - 1) / f; return t; };
+        if (const char *e = getenv("MSDR_MB_FILL")) fill = std::max(1, std::min(cpt, atoi(e)));
+        else while (fill > 1 && tiles_at(fill) * 2 <= (long long)c->ctx->num_cus * 4) fill >>= 1;
+        const long long tiles_part = tiles_at(fill);
         msdr_chain::BlockPart &bp = c->bpart[part];
         bp = msdr_chain::BlockPart();
         bp.offset = tab.size();
@@ -2984,7 +2990,7 @@ static int chain_block_tiles(msdr_chain *c, int n_, const std::function<int(uint
         if (bp.nw == 0 || bp.tpw == 0) { bp.nw = 1; bp.tpw = 1; }
         const size_t per_wg = (size_t)bp.nw * bp.tpw;
         for (auto &g : groups) {
-            const size_t tiles_g = ((g.second - g.first) + cpt - 1) / cpt;
+            const size_t tiles_g = ((g.second - g.first) + fill - 1) / fill;
             for (size_t t0 = 0; t0 < tiles_g; t0 += per_wg) {
                 tab.push_back(key_of(order[g.first])); tab.push_back(0); tab.push_back(0); tab.push_back(0);      // kMbRecHdrInts
                 const size_t base = tab.size();
@@ -2992,8 +2998,8 @@ static int chain_block_tiles(msdr_chain *c, int n_, const std::function<int(uint
                 const size_t cnt = std::min(per_wg, tiles_g - t0);
                 for (size_t t = 0; t < cnt; t++) {           // tile t of this workgroup -> wave t % nw, its slot t / nw
                     const size_t slot = (t % bp.nw) * bp.tpw + t / bp.nw;
-                    for (int k = 0; k < cpt; k++) {
-                        const size_t idx = g.first + (t0 + t) * cpt + k;
+                    for (int k = 0; k < fill; k++) {
+                        const size_t idx = g.first + (t0 + t) * fill + k;
                         if (idx < g.second) tab[base + slot * cpt + k] = (int)order[idx];
                     }
                 }

@@ -161,6 +161,32 @@ def test_block_kernel_agrees_with_wave_stream_kernel(ctx, orc, monkeypatch):
         assert rel_rms(ga[c], gb[c]) < 2e-6, (c, rel_rms(ga[c], gb[c]))
 
 
+@pytest.mark.parametrize("mode", [orclib.AM, orclib.USB])
+def test_block_tile_fill_does_not_change_a_bit(ctx, orc, monkeypatch, mode):
+    """Small batches place fewer channels per tile than a tile holds (so that every SIMD gets a wave); where a channel sits in a tile
+    changes no arithmetic: every fill gives the same bits, the fill the host picks by itself included."""
+    rng = np.random.default_rng(555)
+    ch, n = 53, 24 * 128
+    x = _if(rng, ch, n)
+    ti, tq = ((_lowpass(256),) * 2) if mode == orclib.AM else _hilbert_pair(256)
+    bq = _f32_biquads(orc, 2)
+    outs = []
+    for fill in (None, "1", "2", "4", "8"):
+        if fill is None:
+            monkeypatch.delenv("MSDR_MB_FILL", raising=False)
+        else:
+            monkeypatch.setenv("MSDR_MB_FILL", fill)
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, ti, tq, mixer=msdr.MIXER_FS4, mode=mode, biquad_coeffs=bq)
+        outs.append(run_chain(ctx, chain, x, np.float32, 128))
+        assert _is_block(chain), chain.info()["kernel"]
+    monkeypatch.delenv("MSDR_MB_FILL", raising=False)
+    for o in outs[1:]:
+        assert np.array_equal(o.view(np.uint32), outs[0].view(np.uint32))
+    for c in range(0, ch, 7):
+        want = orc.chain_f32(x[c], mode, ti, tq, SIN4, COS4, bq)
+        assert rel_rms(outs[0][c], want) < TOL
+
+
 def test_block_int16_audio_out(ctx, orc):
     """MSDR_CHAIN_OUT_I16 at block cadence: the play queue's sample type written by the block kernel's store phase."""
     rng = np.random.default_rng(560)

@@ -2343,6 +2343,15 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
         else for (int k = 0; k < P; k++) { oc[k] = ((const float *)cfg->osc_q)[k]; os[k] = ((const float *)cfg->osc_i)[k]; }
         struct Tab { MfmaTableHeader h; std::vector<_Float16> frags; };
         std::vector<Tab> tabs((size_t)c->tapsets * 3 * P);
+        // full rate, long filters: the k-step fragments of a Toeplitz block are 47 taps spread over 1024 entries -- 512 taps x two filters are
+        // 136 KB of LDS and leave room for two waves' windows.  COMPACT layout: the taps themselves (reversed, scaled, hi | lo pieces) in eight
+        // copies shifted by one entry each, so that the 8 consecutive entries a lane needs for ANY k-step are one aligned 16-byte read
+        // (msdr_chain_mfw.hiph, mw_compact_stride): 2 x 19 KB at 512 taps, 6 - 7 waves per CU instead of 2.  What it cannot hold is a block
+        // that is not Toeplitz: the SSB tables then keep the cascade out of their columns (it runs as the lane scan, like 3 - 4 sections).
+        // From 128 taps on (profiles/r05/nco_long_taps.txt); MSDR_FR_COMPACT=0 / 1 overrides (tests, A/B runs).
+        bool compact = fr && N >= 128;
+        if (const char *e = getenv("MSDR_FR_COMPACT")) compact = fr && atoi(e) != 0;
+        const int CS = compact ? mw_compact_stride(H) : 0;
         int bsteps = 0;
         const bool ok = true;
         std::vector<double> M[2];
@@ -2534,7 +2543,7 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
                             M[0][(size_t)i * 32 + b] = m0; M[1][(size_t)i * 32 + b] = m1;
                             maxabs = std::max(maxabs, std::max(std::fabs(m0), std::fabs(m1)));
                         }
-                    const bool fold_iir = numfold && iirfold;
+                    const bool fold_iir = numfold && iirfold && !compact;
                     if (fold_iir) {                                      // B' = B L^T: columns take in the zero-state all-pole response
                         maxabs = 0.0;
                         for (int i = 0; i < KIv; i++) {
@@ -2596,6 +2605,33 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
                             T.h.run[o][src].j0 = (jhi >= 0) ? jlo : 0;
                             T.h.run[o][src].cnt = (jhi >= 0) ? jhi - jlo + 1 : 0;
                             if (o == 1 && src == 0) T.h.acc1_base = share ? 0 : ns;      // (accumulator 1's fragments start behind accumulator 0's two runs)
+                            T.h.bk[o][src] = (o == 1 ? T.h.acc1_base : 0) * 2048;      // where the kernel's step counter meets the run (bytes at step 0)
+                            if (compact) {
+                                // step st of the run = chunk j = j0 + st (after run a: j0b + st - cnta) sits 32 j bytes into the array
+                                const int before = (src == 1) ? T.h.run[o][0].cnt : 0;
+                                if (share && o == 1) { T.h.bk[o][src] = T.h.bk[0][0] - 32 * T.h.run[0][0].j0 + 32 * (T.h.run[o][src].j0 - before); continue; }
+                                if (jhi < 0) continue;
+                                const size_t base = T.frags.size();
+                                T.h.bk[o][src] = (int)(base * 2) + 32 * (T.h.run[o][src].j0 - before);
+                                T.frags.resize(base + (size_t)8 * CS, (_Float16)0.0f);         // 8 copies x (hi | lo) x CS / 2 entries
+                                for (int sh = 0; sh < 8; sh++)
+                                    for (int e = 0; e < CS / 2; e++) {
+                                        // g[u]: the block's entry on the diagonal i - b + 31 = u (window sample i, output column b)
+                                        const int u = e + sh, b = u < 31 ? 31 - u : 0, i = u - 31 + b;
+                                        if (i >= KI) continue;
+                                        double val = M[o][(size_t)(2 * i + src) * 32 + b] * scale;
+#if defined(MSDR_MUTATE) && MSDR_MUTATE == 2
+                                        if (val != 0.0) { int e_; const double f_ = std::frexp(val, &e_); val = std::ldexp(std::nearbyint(std::ldexp(f_, 16)), e_ - 16); }
+#endif
+                                        const _Float16 vh = (_Float16)val;
+                                        T.frags[base + (size_t)sh * (CS / 2) + e] = vh;
+                                        T.frags[base + (size_t)(8 + sh) * (CS / 2) + e] = (_Float16)(val - (double)vh);
+#if defined(MSDR_MUTATE) && MSDR_MUTATE == 1
+                                        T.frags[base + (size_t)(8 + sh) * (CS / 2) + e] = (_Float16)0.0f;
+#endif
+                                    }
+                                continue;
+                            }
                             if (share && o == 1) continue;                             // same chunks, same values as run[0][0]: stored once
                             for (int j = jlo; j <= jhi; j++, ns++) {
                                 const size_t base = T.frags.size();
@@ -2615,6 +2651,9 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
                                     }
                             }
                         }
+                    if (compact) ns = (int)((T.frags.size() * 2 + 2047) / 2048);          // (LDS sizes are counted in 2 KB steps everywhere)
+                    T.frags.resize((size_t)ns * 1024, (_Float16)0.0f);
+                    T.h.cs = CS; T.h.bstep = compact ? 32 : 2048;
                     T.h.nsteps = ns;
                     bsteps = std::max(bsteps, ns);
                 }
@@ -2654,10 +2693,14 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
                     const int on_cu = wgs * w, eff = on_cu >= 4 ? 4 * (on_cu / 4) : on_cu;
                     if (eff > best_eff) { best_eff = eff; best = on_cu; c->mfw_nw = w; }
                 }
+                if (const char *e = getenv("MSDR_MFW_NW")) {     // A/B runs: a given number of waves per workgroup, where it fits (one workgroup per CU then)
+                    const int w = atoi(e);
+                    if (w >= 1 && w <= 16 && mw_lds_bytes(H, bsteps, w, fr) <= 160 * 1024) { c->mfw_nw = w; best = w * std::max<int>(1, std::min<int>((int)((160 * 1024) / mw_lds_bytes(H, bsteps, w, fr)), 16 / w)); }
+                }
                 c->mfw_waves_per_cu = best;
                 if (best > 0) rc = dzalloc(ctx, (size_t)c->channels * kBqStateFloats, &c->d_bq_state_alt);
                 if (!rc && iirfold && !iirc.empty()) rc = upload(ctx, iirc, &c->d_mw_iir);
-                c->mfw_ssb_fold = iirfold && c->d_mw_iir; c->mfw_am_fold = amfold && c->d_mw_iir;
+                c->mfw_ssb_fold = iirfold && !compact && c->d_mw_iir; c->mfw_am_fold = amfold && c->d_mw_iir;
                 if (best <= 0) c->mf_ok = false;               // not even one wave's window fits next to the fragments: the VALU kernels run
                 // (full-rate layout: a lone wave per CU waits out every LDS round trip of a 60-step burst on its own -- two waves were 1.4 x the
                 //  vector-ALU kernel at 384 taps, profiles/r05/nco_long_taps.txt; one is not taken)

@@ -420,22 +420,26 @@ def test_chain_f32_am_with_non_fs4_nco(ctx, orc, engine):
 
 
 # ---------------------------------------------------------------- fp32, long FIRs behind a general oscillator table ---
-@pytest.mark.parametrize("ntaps", [248, 257, 513])
-@pytest.mark.parametrize("mode", [orclib.LSB, orclib.USB, orclib.AM])
-def test_chain_f32_long_fir_behind_a_general_table_vs_oracle(ctx, orc, ntaps, mode):
-    """More than 247 taps behind an oscillator table that is NOT short-periodic (every AudioEffectFreqConv table repeats with the 128-sample
-    block whatever is in it, freq_conv.cpp:67-103).  Round 5: the full-rate matrix-core layout takes every tap count whose fragments fit LDS
-    beside a wave's windows (to ~400 taps; round 4 stopped at 247 and fell to the vector ALU: 256 taps 0.07 -> 0.17 of the roof on c4's
-    shape), and an envelope table whose two streams meet ONE low-pass (hI == hQ, the reference's AM case: this test's AM rows) stores its
-    fragments once.  At 513 taps the SSB tables of the same tap set (every chain carries all three flavours: a retune may ask for any) do not
-    fit: chain_kernel<ArithF32> answers (the as-written evaluation)."""
-    rng = np.random.default_rng(ntaps * 3 + mode)
+def _general_table_case(ntaps, mode):
     if mode == orclib.AM:
         hi = (np.sinc(2 * 2800 / 24000 * (np.arange(ntaps) - (ntaps - 1) / 2)) * np.kaiser(ntaps, 7.0)).astype(np.float32)
         hi /= hi.sum()
         hq = hi
     else:
         hi, hq = _hilbert_pair(ntaps)
+    return hi, hq
+
+
+@pytest.mark.parametrize("ntaps", [130, 248, 257, 513, 1021])
+@pytest.mark.parametrize("mode", [orclib.LSB, orclib.USB, orclib.AM])
+def test_chain_f32_long_fir_behind_a_general_table_vs_oracle(ctx, orc, ntaps, mode):
+    """Long filters behind an oscillator table that is NOT short-periodic (every AudioEffectFreqConv table repeats with the 128-sample block
+    whatever is in it, freq_conv.cpp:67-103).  Round 4 stopped at 247 taps and fell to the vector ALU (256 taps 0.07, 512 taps 0.04 of the roof
+    on c4's shape).  Round 5: from 128 taps on the full-rate layout keeps the B operand as shifted copies of the taps (mw_compact_stride: 19 KB
+    per filter at 512 taps where the k-step fragments are 68 KB), so every length to 1021+ taps stays on the matrix cores: 256 taps 0.18, 512
+    taps 0.098 = 1.8 PFLOP/s executed (profiles/r05/nco_long_taps.txt)."""
+    rng = np.random.default_rng(ntaps * 3 + mode)
+    hi, hq = _general_table_case(ntaps, mode)
     oi, oq = _nco(128, 5)                                   # 5 cycles per 128 samples: period 128
     bq = _f32_biquads(orc, 2)
     x = rng.integers(-8000, 8001, (3, 20011)).astype(np.int16)
@@ -444,11 +448,40 @@ def test_chain_f32_long_fir_behind_a_general_table_vs_oracle(ctx, orc, ntaps, mo
         chain.reset()
         got = run_chain(ctx, chain, x, np.float32, block)
         if block != 128:
-            want_kernel = "chain_kernel<ArithF32>" if ntaps > 500 else "chain_mfw_kernel<2> full-rate NCO streams"
-            assert chain.info()["kernel"] == want_kernel, chain.info()
+            assert chain.info()["kernel"] == "chain_mfw_kernel<2> full-rate NCO streams", chain.info()
         for c in range(3):
             want = orc.chain_f32(x[c], mode, hi, hq, oi, oq, bq)
             assert rel_rms(got[c], want) < TOL, (block, c, rel_rms(got[c], want))
+
+
+@pytest.mark.parametrize("stages", [0, 1, 2, 4])
+@pytest.mark.parametrize("ntaps", [57, 100, 248, 330])
+def test_chain_f32_full_rate_layouts_agree(ctx, orc, monkeypatch, ntaps, stages):
+    """The two B-operand layouts of the full-rate kernel (k-step fragments, MSDR_FR_COMPACT=0; shifted copies of the taps, =1) on the same
+    chains, every flavour (LSB / USB / envelope with two different low-passes / envelope with one) and section count: both inside the
+    tolerance against the oracle.  (With 1 - 2 sections the fragment layout folds the cascade into its SSB columns, the compact one runs it
+    as the lane scan: the two differ by rounding there, elsewhere they run the same products in the same order -- bit-identical.)"""
+    rng = np.random.default_rng(ntaps * 7 + stages)
+    oi, oq = _nco(128, 9)
+    bq = _f32_biquads(orc, stages) if stages else None
+    x = rng.integers(-8000, 8001, (4, 9000)).astype(np.int16)
+    modes = np.array([orclib.LSB, orclib.USB, orclib.AM, orclib.CW], np.int32)
+    hi, hq = _hilbert_pair(ntaps)
+    lp, _ = _general_table_case(ntaps, orclib.AM)
+    for ti, tq in ((hi, hq), (lp, lp)):
+        outs = []
+        for layout in ("0", "1"):
+            monkeypatch.setenv("MSDR_FR_COMPACT", layout)
+            chain = msdr.Chain(ctx, msdr.ARITH_F32, 4, ti, tq, mixer=msdr.MIXER_NCO, modes=modes, osc_i=oi, osc_q=oq, biquad_coeffs=bq)
+            outs.append(run_chain(ctx, chain, x, np.float32, 3001))
+            assert chain.info()["kernel"].endswith("full-rate NCO streams"), chain.info()
+        monkeypatch.delenv("MSDR_FR_COMPACT")
+        for c in range(4):
+            want = orc.chain_f32(x[c], modes[c], ti, tq, oi, oq, bq)
+            for o in outs:
+                assert rel_rms(o[c], want) < TOL, (ntaps, stages, c, rel_rms(o[c], want))
+            if stages in (0, 4) or modes[c] in (orclib.AM, orclib.CW):
+                assert np.array_equal(outs[0][c].view(np.uint32), outs[1][c].view(np.uint32)), (ntaps, stages, c)
 
 
 def test_chain_f32_valu_envelope_with_distinct_branches(ctx, orc):

@@ -141,15 +141,16 @@ def test_fp32_contract_on_the_fuzzers_cases(ctx, orc):
 
 def test_many_sections_behind_the_general_kernel_run_in_cmsis_order(ctx, orc):
     """The one case of round 3's fuzz records that no criterion excused (profiles/r03/fuzz_kernels_606_final.txt: 277 taps behind a
-    128-periodic table, four sections, chain_kernel<ArithF32>, 1.07e-5; from round 5 that tap count runs on chain_mfw_kernel's full-rate layout and this
-    test draws 430 .. 499 taps): three or four sections behind the general kernel -- the only
-    place where the block-parallel cascade runs with 12-sample lanes -- now run section by section in CMSIS order."""
+    128-periodic table, four sections, chain_kernel<ArithF32>, 1.07e-5; from round 5 every 128-entry table runs on chain_mfw_kernel's full-rate
+    layout whatever the tap count, and this test draws its cases behind a 96-entry table -- 96 does not divide the block, the general kernel
+    answers): three or four sections behind the general kernel -- the only place where the block-parallel cascade runs with 12-sample lanes --
+    now run section by section in CMSIS order."""
     rng = np.random.default_rng(606)
-    k = np.arange(B)
-    oi = (np.round(32767 * np.sin(2 * np.pi * k / 128)).astype(np.int16) / 32768.0).astype(np.float32)
-    oq = (np.round(32767 * np.cos(2 * np.pi * k / 128)).astype(np.int16) / 32768.0).astype(np.float32)
+    k = np.arange(96)
+    oi = (np.round(32767 * np.sin(2 * np.pi * k / 96)).astype(np.int16) / 32768.0).astype(np.float32)
+    oq = (np.round(32767 * np.cos(2 * np.pi * k / 96)).astype(np.int16) / 32768.0).astype(np.float32)
     for trial in range(12):
-        ntaps, stages = int(rng.integers(430, 500)), int(rng.integers(3, 5))         # (round 5: 248 .. 400 taps run on the full-rate matrix-core layout now; past that the general kernel)
+        ntaps, stages = int(rng.integers(248, 500)), int(rng.integers(3, 5))
         hi = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
         hq = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
         rows = []

@@ -33,7 +33,8 @@ CASES = {
     "lsb100_2sec": dict(taps=100, mode=orclib.LSB, stages=2, kernel="chain_mfw_kernel<2>"),
     "usb100_4sec": dict(taps=100, mode=orclib.USB, stages=4, kernel="chain_mfw_kernel<4>"),
     "valu_fold": dict(taps=100, mode=orclib.LSB, stages=2, flags=msdr.CHAIN_NO_MFMA, kernel="chain_fold_kernel<4>"),
-    "general_table_long_fir": dict(taps=460, mode=orclib.USB, stages=1, nco=(128, 5), kernel="chain_kernel<ArithF32>"),      # (round 5: the full-rate layout takes 260 taps now; 460 do not fit LDS)
+    "general_table_long_fir": dict(taps=460, mode=orclib.USB, stages=1, nco=(128, 5), kernel="chain_mfw_kernel<1> full-rate NCO streams"),   # (round 5: the compact B layout keeps it on the matrix cores)
+    "table_of_another_period": dict(taps=260, mode=orclib.USB, stages=1, nco=(96, 5, 96), kernel="chain_kernel<ArithF32>"),     # a 96-entry table: 96 does not divide 128, no block-periodic streams -- the as-written kernel answers
     "general_table_260_taps": dict(taps=260, mode=orclib.USB, stages=1, nco=(128, 5), kernel="chain_mfw_kernel<1> full-rate NCO streams"),
     "full_rate_table": dict(taps=100, mode=orclib.LSB, stages=2, nco=(128, 5), kernel="chain_mfw_kernel<2> full-rate NCO streams"),
 }

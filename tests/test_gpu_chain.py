@@ -437,7 +437,7 @@ def test_chain_f32_long_fir_behind_a_general_table_vs_oracle(ctx, orc, ntaps, mo
     whatever is in it, freq_conv.cpp:67-103).  Round 4 stopped at 247 taps and fell to the vector ALU (256 taps 0.07, 512 taps 0.04 of the roof
     on c4's shape).  Round 5: from 128 taps on the full-rate layout keeps the B operand as shifted copies of the taps (mw_compact_stride: 19 KB
     per filter at 512 taps where the k-step fragments are 68 KB), so every length to 1021+ taps stays on the matrix cores: 256 taps 0.18, 512
-    taps 0.098 = 1.8 PFLOP/s executed (profiles/r05/nco_long_taps.txt)."""
+    taps 0.098 = 0.90 PFLOP/s executed (profiles/r05/nco_long_taps.txt)."""
     rng = np.random.default_rng(ntaps * 3 + mode)
     hi, hq = _general_table_case(ntaps, mode)
     oi, oq = _nco(128, 5)                                   # 5 cycles per 128 samples: period 128

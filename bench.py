@@ -77,9 +77,12 @@ def compact_record(rec):
     if rec is None:
         return None
     r, par = rec.get("roofline", {}), rec.get("parity") or {}
-    pv = par.get("rel_rms_worst", par.get("mismatching_samples", par.get("max_abs_lsb")))
+    # what the parity figure is, by its key: relative RMS error against the oracle (fp32), mismatching samples (integer paths: 0 = bit-exact),
+    # or the largest difference in int16 steps (int16 audio out of the fp32 chain: tolerance 1)
+    pkey = "rel_rms_worst" if "rel_rms_worst" in par else "mismatching_samples" if "mismatching_samples" in par else "max_abs_lsb"
     c = {"Msps": rec.get("value"), "ms_per_step": rec.get("ms_per_step"), "kernel_ms": r.get("kernel_ms"), "frac": r.get("frac"),
-         "bound": r.get("bound"), "sclk_mhz": r.get("sclk_mhz"), "power_w": r.get("power_w"), "parity": pv,
+         "bound": r.get("bound"), "sclk_mhz": r.get("sclk_mhz"), "power_w": r.get("power_w"),
+         {"rel_rms_worst": "parity", "mismatching_samples": "parity_mismatches", "max_abs_lsb": "parity_max_lsb"}[pkey]: par.get(pkey),
          "kernel": str(rec.get("config", {}).get("kernel", ""))[:48]}
     for k in ("binding_frac", "mfma_frac_of_sustained", "step_ms", "node_pass_ms", "traffic", "tick_us", "launches_per_step", "graph_tick_us"):
         if r.get(k) is not None:

@@ -32,7 +32,7 @@ def test_two_rank_rehearsal_prints_one_complete_line():
     for name, rec in recs.items():
         assert rec["frac"] > 0 and rec["kernel_ms"] > 0 and rec["ms_per_step"] >= rec["kernel_ms"] * 0.98, name
         if name not in ("fir", "fir512"):                        # (the FIR stage's parity needs the CPU leg, off here)
-            assert rec["parity"] is not None, name
+            assert any(rec.get(k) is not None for k in ("parity", "parity_mismatches", "parity_max_lsb")), name
     assert d["gather"]["all_gather_ms"] > 0 and d["gather"]["gather_to_root_ms"] > 0
     assert "rehearsal" in d
     full = json.load(open(os.path.join(ROOT, "bench_full.json")))           # the full record beside the script

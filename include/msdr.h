@@ -406,7 +406,10 @@ typedef struct {
                                         arm_float_to_q15 converts (prototype arm_math.h:6592; CMSIS-DSP 1.5.x: (q15_t) __SSAT((q31_t)(x * 32768.0f), 16)): 4 B
                                         per sample through HBM instead of 6, and half the bytes in the audio gather.  The matrix-core kernels convert in
                                         their store phase; chains that run a pass behind the main kernel (CMSIS-order cascade, PLL / LMS channels) or
-                                        one of the vector-ALU kernels go through an fp32 scratch block batch owned by the chain.  Ignored by Q15 chains. */
+                                        one of the vector-ALU kernels go through an fp32 scratch block batch owned by the chain: channels x n_samples x 4 bytes,
+                                        allocated at the first such call and grown (with a stream synchronisation) when a longer call comes, plus one
+                                        conversion pass over it -- 10 B per sample through HBM, not 4; call such chains in blocks, not in 2^18-sample
+                                        calls (4 GB on c3's shape).  Ignored by Q15 chains. */
 /* any other bit in msdr_chain_config.flags is refused with MSDR_STATUS_ARGUMENT_ERROR */
 #define MSDR_CHAIN_NO_MFMA 8u        /* never run the FIR on the matrix cores (F32: split-fp16 MFMA kernel; Q15: byte-split i8 MFMA kernel) */
 #define MSDR_CHAIN_FOLD_ANY_PERIOD 64u /* F32, NCO: fold the mixer into the taps (matrix-core kernel) also when the oscillator table's only period is its

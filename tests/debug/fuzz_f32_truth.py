@@ -92,11 +92,15 @@ while time.time() < t_end:
         over += 1
         pre = orc.chain_f32(x[c], modes[c], hi, hq, oi, oq, None)             # the cascade's input
         lvl = max(1.0, float(np.sqrt((pre.astype(np.float64) ** 2).mean() / max((want.astype(np.float64) ** 2).mean(), 1e-300))))
-        if e_go < 1e-5 * lvl and only < 0:
-            attenuating += 1
-            continue
         t = truth64(x[c], int(modes[c]), hi, hq, oi, oq, bq)
         e_gpu, e_orc = rel_rms(got[c], t), rel_rms(want, t)
+        if e_go < 1e-5 * lvl and only < 0:
+            # inside the contract by its input-level clause; the float64 figures are printed all the same (a reader can see how the two fp32
+            # evaluations sit against the exact result)
+            attenuating += 1
+            print("attenuating case %d: gpu-oracle %.2e (level %.1f) | gpu-f64 %.2e  oracle-f64 %.2e | taps %d stages %d %s"
+                  % (case, e_go, lvl, e_gpu, e_orc, ntaps, stages, chain.info()["kernel"]), flush=True)
+            continue
         worst = max(worst, e_gpu / max(e_orc, 1e-12))
         bad = e_gpu > 2 * e_orc + msdr.biquad_cascade_info(bq)[1] + 1e-6 * lvl  # the contract of include/msdr.h (fp32_noise: the cascade's own figure; lvl: its input's level)
         defects += bad

@@ -102,6 +102,9 @@ def _judge(ctx, orc, cs, tag, stats):
                 pre = orc.chain_f32(cs["x"][c], cs["modes"][c], cs["hi"], cs["hq"], cs["oi"], cs["oq"], None)
                 lvl = max(1.0, float(np.sqrt((pre.astype(np.float64) ** 2).mean() / max((want.astype(np.float64) ** 2).mean(), 1e-300))))
             stats["tight_worst"] = max(stats.get("tight_worst", 0.0), e_gpu / (2 * e_orc + noise + 1e-6 * lvl))
+            # (reported, not asserted: the same bound with the cascade's noise figure capped at the oracle's own distance -- "never more than
+            #  three times as far from the exact result as the CMSIS order")
+            stats["capped_worst"] = max(stats.get("capped_worst", 0.0), e_gpu / (2 * e_orc + min(noise, e_orc) + 1e-6 * lvl))
             assert e_gpu <= 2 * e_orc + noise + 1e-6 * lvl, (tag, int(c), kernel, "TIGHT clause: gpu-oracle %.2e gpu-f64 %.2e oracle-f64 %.2e level %.1f fp32_noise %.2e" % (e_go, e_gpu, e_orc, lvl, noise))
             continue
         stats["over"] += 1
@@ -134,7 +137,8 @@ def test_fp32_contract_on_the_fuzzers_cases(ctx, orc):
         for case in cases:
             _judge(ctx, orc, _case(orc, seed, case), (seed, case), stats)
     print("fp32 contract: %d channel checks, %d beyond 1e-5 of the fp32 oracle: %d within 1e-5 of the cascade's input level, the others judged against float64 (worst e_gpu / e_orc %.2f); "
-          "every case against float64: worst e_gpu / (2 e_orc + fp32_noise + 1e-6 level) = %.2f" % (stats["checks"], stats["over"], stats["attenuating"], stats["worst"], stats.get("tight_worst", 0.0)))
+          "every case against float64: worst e_gpu / (2 e_orc + fp32_noise + 1e-6 level) = %.2f; with fp32_noise capped at e_orc: %.2f"
+          % (stats["checks"], stats["over"], stats["attenuating"], stats["worst"], stats.get("tight_worst", 0.0), stats.get("capped_worst", 0.0)))
     assert stats["checks"] >= 200
     assert stats["over"] >= 1, "no case exercised the float64 criterion: the seeds no longer reproduce the fuzzers' cases"
 

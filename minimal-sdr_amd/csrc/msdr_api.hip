@@ -3442,6 +3442,15 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         if ((n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 && c->channels % (unsigned)per_group == 0 &&
             c->nodes[0]->max_stage == 0 && c->nodes[1]->max_stage == 0) {
             // one stage per node (the reference's configuration): the recursions alone on two waves, the input products element-wise on the others
+            // (one 128-sample block, the reference's cadence: the pipeline over sub-slabs inside the block, while its 16-channel workgroups find a
+            //  CU each -- 4096 channels: 15.1 -> 13.2 us per tick; at 8192 the slab kernel is ahead again, 16.6 vs 17.3, tools/r05_nodes_x.sh;
+            //  MSDR_BIQUAD_BLK=0 / 1 overrides)
+            const char *blk_env = getenv("MSDR_BIQUAD_BLK");
+            const int blk_force = blk_env ? atoi(blk_env) : -1;
+            if (n_samples == 128 && (c->channels & 15u) == 0 && (blk_force == 1 || (blk_force < 0 && c->channels / kTqbCh <= (uint32_t)c->ctx->num_cus)))
+                hipLaunchKernelGGL(biquad_teensy_blk_kernel, dim3(c->channels / kTqbCh), dim3(kTqbThreads), tqb_lds_bytes(), c->ctx->stream, (short *)d_audio,
+                                   c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels);
+            else
             if (per_group == 64)
                 hipLaunchKernelGGL((biquad_teensy_pipe4_kernel<2, 64>), dim3(c->channels / 64), dim3(tq4_threads(64)), tq4_lds_bytes(64), c->ctx->stream, (short *)d_audio,
                                    c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);

@@ -336,6 +336,34 @@ def test_block_q15_reference_graph_64_ticks_bit_exact(ctx, orc, golden, mixer, s
             assert np.array_equal(got[c, lo * 128:hi * 128], want), (c, lo, hi, m, ts)
 
 
+@pytest.mark.parametrize("ch", [16, 48, 4096])
+def test_block_q15_nodes_sub_slab_pipeline_bit_exact(ctx, orc, golden, monkeypatch, ch):
+    """biquad1_dac -> biquad2_dac at block cadence on channel counts the sub-slab kernel takes (multiples of 16: biquad_teensy_blk_kernel, the
+    two recursions pipelined over 16-sample sub-slabs inside the one 128-sample block): 40 ticks against the oracle, state carried from tick to
+    tick, full-scale and -32768 inputs; and the same stream through the slab kernels (MSDR_BIQUAD_BLK=0): identical."""
+    rng = np.random.default_rng(640 + ch)
+    ticks = 40
+    taps = golden["fir/taps_am102"]
+    lp, nt = _ref_nodes(orc)
+    x = rng.integers(-32768, 32768, (ch, ticks * 128)).astype(np.int16)
+    x[3] = -32768
+    x[5] = 32767
+    outs = []
+    for force in (None, "0"):
+        if force is None:
+            monkeypatch.delenv("MSDR_BIQUAD_BLK", raising=False)
+        else:
+            monkeypatch.setenv("MSDR_BIQUAD_BLK", force)
+        chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, taps, taps, mode=orclib.AM, biquad_nodes=[[lp], [nt]])
+        outs.append(run_chain(ctx, chain, x, np.int16, 128))
+        assert _is_qblock(chain), chain.info()["kernel"]
+    monkeypatch.delenv("MSDR_BIQUAD_BLK", raising=False)
+    assert np.array_equal(outs[0], outs[1])
+    for c in sorted(set([0, 3, 5, 15, ch - 1, ch // 2])):
+        want = orc.chain_q15(x[c], orclib.AM, taps, taps, biquads=[orc.biquad_teensy_new([lp]), orc.biquad_teensy_new([nt])])
+        assert np.array_equal(outs[0][c], want), c
+
+
 def test_block_q15_matches_reference_golden_and_stream_kernel(ctx, golden, monkeypatch):
     """The reference-generated golden chain vectors at block cadence, and the same through the streaming kernel (MSDR_NO_BLOCK=1)."""
     sigs = ["am", "tones", "noise", "full"]

@@ -13,5 +13,5 @@ esac
 # round 5: the same live-update fuzzer at the reference's cadence (FUZZ_BLOCK=1: calls of 32 .. 512 samples: the block kernels)
 if [ "${1:-a}" = "e" ]; then
   export FUZZ_BLOCK=1
-  run fuzz_live 300 5301; run fuzz_live 300 5302
+  run fuzz_live 300 ${SEED1:-5301}; run fuzz_live 300 ${SEED2:-5302}
 fi

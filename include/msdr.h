@@ -448,7 +448,9 @@ int msdr_chain_set_mode(msdr_chain *chain, uint32_t channel, int32_t mode, int32
  *   The number of stages is fixed at creation, as numStages is in CMSIS.
  * msdr_chain_set_osc: new contents for the NCO tables (same osc_len) -- AudioEffectFreqConv reads the global Osc_I_buffer_i /
  *   Osc_Q_buffer_i on every update() (freq_conv.h:33-34, freq_conv.cpp:70-103), so a sketch that rewrites them retunes the mixer
- *   without touching anything else; the position in the table carries on. */
+ *   without touching anything else; the position in the table carries on.  The samples already in the FIR history were mixed with the
+ *   table of their own time, as in the reference (the mixer runs in front of the FIR's state buffer): the library keeps up to 16 earlier
+ *   tables for as long as the history holds samples of theirs (a 17th change inside ONE history length drops the oldest). */
 int msdr_chain_set_taps(msdr_chain *chain, uint32_t tapset, const void *coeffs_i, const void *coeffs_q);
 int msdr_chain_set_node_coefficients(msdr_chain *chain, uint32_t node, uint32_t stage, const int32_t coef[5]);
 int msdr_chain_set_biquad_coeffs(msdr_chain *chain, const float32_t *biquad_coeffs);

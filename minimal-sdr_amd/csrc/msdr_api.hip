@@ -3112,7 +3112,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         OscHistory oh;
         memset(&oh, 0, sizeof oh);
         for (const auto &o : c->osc_pending) {
-            if (oh.n >= 4) break;
+            if (oh.n >= kOscHistMax) break;
             oh.tab[oh.n] = o.d_tab; oh.sw[oh.n] = -o.elapsed; oh.n++;
         }
         if (!c->d_osc_hist) HIP_TRY(hipMalloc((void **)&c->d_osc_hist, sizeof(OscHistory)));
@@ -3294,6 +3294,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         HIP_TRY(hipEventRecord(e0, c->ctx->stream));
     }
     const char *kname = f32 ? "chain_kernel<ArithF32>" : "chain_kernel<ArithQ15>";
+    bool nodes_fused = false;            // Q15 block cadence: the biquad nodes ran inside chain_q15mb_kernel
     unsigned block = kThreads;
     size_t lds_used = lds;
     if (use_mfb) {
@@ -3363,19 +3364,29 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     else if (f32) (void)launch_chain_generic(c->ctx->stream, false, grid, lds, p);
     else if (use_qb) {
         grid = 0;
+        // the two biquad nodes as the kernel's second phase: the reference's configuration (one stage per node, nothing between the
+        // demodulator and the nodes), one 128-sample block, and every launch of this call with one tile per wave on three or more waves
+        // (small batches: up to 16 384 channels of one flavour on this part); MSDR_Q15_NO_FUSE=1: the node kernel behind it as before
+        nodes_fused = c->nnodes == 2 && c->nodes[0]->max_stage == 0 && c->nodes[1]->max_stage == 0 && n_samples == 128 && !pll_active &&
+                      !(c->anr && (c->d_anr_on || c->anr_all > 0)) && !getenv("MSDR_Q15_NO_FUSE");
+        for (int part = 0; part < 2 && nodes_fused; part++) {
+            const msdr_chain::BlockPart &bp = c->bpart[part];
+            if (bp.wgs && (bp.tpw != 1 || bp.nw < 3 || qb_nodes_lds_bytes(c->qm_halo, 128, c->qm_bsteps, (int)bp.nw) > 160 * 1024)) nodes_fused = false;
+        }
         for (int part = 0; part < 2; part++) {
             const msdr_chain::BlockPart &bp = c->bpart[part];
             if (bp.wgs == 0) continue;
             ChainParams q = p;
             q.mf_tab = c->d_qm_tab; q.mf_stride = c->qm_stride; q.mf_halo = c->qm_halo; q.mf_bsteps = c->qm_bsteps;
             q.mf_units = c->d_btiles + bp.offset; q.mf_nw = (int)bp.nw; q.nseg = (int)bp.tpw;
-            lds_used = qb_lds_bytes(c->qm_halo, (int)n_samples, c->qm_bsteps, (int)bp.nw, (int)bp.tpw);
+            lds_used = nodes_fused ? qb_nodes_lds_bytes(c->qm_halo, 128, c->qm_bsteps, (int)bp.nw) : qb_lds_bytes(c->qm_halo, (int)n_samples, c->qm_bsteps, (int)bp.nw, (int)bp.tpw);
+            if (nodes_fused) { q.bq_state = reinterpret_cast<float *>(c->nodes[0]->d_defs); q.bq_state_out = reinterpret_cast<float *>(c->nodes[1]->d_defs); }
             const int flavour = part == 0 ? 0 : (c->sqrt_kind == 1 ? 2 : 1);
-            if (launch_chain_q15mb(c->ctx->stream, flavour, bp.wgs, bp.nw * 64, lds_used, q) != hipSuccess)
+            if (launch_chain_q15mb(c->ctx->stream, flavour, nodes_fused, bp.wgs, bp.nw * 64, lds_used, q) != hipSuccess)
                 return fail(MSDR_STATUS_HIP_ERROR, "chain_q15mb_kernel launch failed");
             grid += bp.wgs; block = bp.nw * 64;
         }
-        kname = "chain_q15mb_kernel (channel-batched block tiles)";
+        kname = nodes_fused ? "chain_q15mb_kernel (block tiles) + both biquad nodes" : "chain_q15mb_kernel (channel-batched block tiles)";
     }
     else if (use_qm) {
         // channels grouped by (tap set, flavour): a workgroup's waves share one table; one launch per group in use
@@ -3436,7 +3447,7 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     if (c->anr && (c->d_anr_on || c->anr_all > 0))      // LMS notch / noise reduction (.ino:702-770), then the biquad nodes
         if (int rc = msdr_anr_q15(c->anr, c->d_anr_on, c->anr_all, (q15_t *)d_audio, (uint32_t)n_samples)) return rc;
 
-    if (c->nnodes == 2) {      // biquad1_dac -> biquad2_dac in one pass over the audio
+    if (c->nnodes == 2 && !nodes_fused) {      // biquad1_dac -> biquad2_dac in one pass over the audio
         const bool slabs = (c->channels & 63u) == 0 && (n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0;
         const int per_group = c->nodes[0]->pipe_ch ? c->nodes[0]->pipe_ch : 64;
         if ((n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 && c->channels % (unsigned)per_group == 0 &&
@@ -3853,9 +3864,15 @@ static int chain_rebuild_keep_folded(msdr_chain *c, const ChainCfgStore &edited,
     if (int rc = chain_rebuild(c, edited, osc_changes ? &old_osc : nullptr)) return rc;
     if (osc_changes) {
         // the samples in the FIR history were mixed with the old tables when they arrived: keep those for as long as the history holds
-        // such samples (at most 4 generations; a fifth change inside one history length drops the oldest)
-        if (c->osc_pending.size() >= 4) { hipFree(c->osc_pending.front().d_tab); c->osc_pending.erase(c->osc_pending.begin()); }
-        c->osc_pending.push_back(msdr_chain::OscPending{old_osc, 0});
+        // such samples.  A table that was replaced before any sample arrived under it (two changes with no call in between) mixed nothing:
+        // it is not a generation (tests/debug/fuzz_live.py seed 5312 case 23466: five changes inside one history length, two of them such,
+        // used up round 4's four slots and the oldest REAL generation was dropped: 0.26 of the output).  At most kOscHistMax generations; one
+        // more inside a single history length drops the oldest (include/msdr.h says so).
+        if (!c->osc_pending.empty() && c->osc_pending.back().elapsed == 0) hipFree(old_osc);
+        else {
+            if (c->osc_pending.size() >= (size_t)kOscHistMax) { hipFree(c->osc_pending.front().d_tab); c->osc_pending.erase(c->osc_pending.begin()); }
+            c->osc_pending.push_back(msdr_chain::OscPending{old_osc, 0});
+        }
         c->force_generic = true;
     }
     if (!fix.empty() && c->d_bq_state) {

@@ -41,8 +41,17 @@ hipError_t launch_chain_mfb(hipStream_t stream, int stages, bool am, unsigned gr
     return hipGetLastError();
 }
 
-hipError_t launch_chain_q15mb(hipStream_t stream, int flavour, unsigned grid, unsigned block, size_t lds, const ChainParams &p)
+hipError_t launch_chain_q15mb(hipStream_t stream, int flavour, bool nodes, unsigned grid, unsigned block, size_t lds, const ChainParams &p)
 {
+    if (nodes) {
+        switch (flavour) {
+        case 0: hipLaunchKernelGGL((chain_q15mb_kernel<0, true>), dim3(grid), dim3(block), lds, stream, p); break;
+        case 1: hipLaunchKernelGGL((chain_q15mb_kernel<1, true>), dim3(grid), dim3(block), lds, stream, p); break;
+        case 2: hipLaunchKernelGGL((chain_q15mb_kernel<2, true>), dim3(grid), dim3(block), lds, stream, p); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (flavour) {
     case 0: hipLaunchKernelGGL((chain_q15mb_kernel<0>), dim3(grid), dim3(block), lds, stream, p); break;
     case 1: hipLaunchKernelGGL((chain_q15mb_kernel<1>), dim3(grid), dim3(block), lds, stream, p); break;

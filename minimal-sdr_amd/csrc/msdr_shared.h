@@ -52,7 +52,8 @@ constexpr int kBqStateFloats = 16;
 // matrix-core kernels are at their register budget, every kernel argument costs them scalar registers).  A carried history sample at
 // time t < sw[k] (t relative to the call, so sw <= 0) was mixed with table k when it arrived (freq_conv.cpp:70-103 mixes each block with
 // the tables as they are at that update()), and chain_kernel<Arith> mixes it with that table again.
-struct OscHistory { const void *tab[4]; long long sw[4]; int n; };
+constexpr int kOscHistMax = 16;      // oscillator tables that can still have samples in one FIR history (msdr_chain_set_osc)
+struct OscHistory { const void *tab[kOscHistMax]; long long sw[kOscHistMax]; int n; };
 
 constexpr int kChainOutI16 = 0x40000000;
 

@@ -364,6 +364,54 @@ def test_block_q15_nodes_sub_slab_pipeline_bit_exact(ctx, orc, golden, monkeypat
         assert np.array_equal(outs[0][c], want), c
 
 
+@pytest.mark.parametrize("nw", ["3", "4", "8"])
+@pytest.mark.parametrize("mixed", [False, True])
+def test_block_q15_nodes_inside_the_chain_kernel_bit_exact(ctx, orc, golden, monkeypatch, nw, mixed):
+    """The two biquad nodes as chain_q15mb_kernel's second phase (one tile per wave on three or more waves: what the host picks for small
+    batches; forced here on a small chain by MSDR_MB_NW): 30 ticks with retunes and a node rewrite in between against the oracle, state
+    carried from tick to tick; ragged channel counts (idle slots, idle waves); SSB and envelope channels mixed = two launches, each with its
+    own node phase; and the same stream with the node kernel behind the chain kernel (MSDR_Q15_NO_FUSE=1): identical."""
+    rng = np.random.default_rng(660 + int(nw) + 10 * mixed)
+    ch, ticks = 83, 30
+    pad = lambda t: np.concatenate([np.zeros(102 - t.size, np.int16), t])
+    sets_i = [golden["fir/taps_am102"], pad(golden["taps/FIR_SSB_I_coeffs"])]
+    sets_q = [golden["fir/taps_am102"], pad(golden["taps/FIR_SSB_Q_coeffs"])]
+    lp, nt = _ref_nodes(orc)
+    modes0 = (rng.integers(1, 5, ch) if mixed else np.full(ch, orclib.AM)).astype(np.int32)
+    tapsets0 = (rng.integers(0, 2, ch) if mixed else np.zeros(ch)).astype(np.int32)
+    x = rng.integers(-32768, 32768, (ch, ticks * 128)).astype(np.int16)
+    x[3] = -32768
+    outs = []
+    monkeypatch.setenv("MSDR_MB_NW", nw)
+    for fuse in (True, False):
+        if fuse:
+            monkeypatch.delenv("MSDR_Q15_NO_FUSE", raising=False)
+        else:
+            monkeypatch.setenv("MSDR_Q15_NO_FUSE", "1")
+        modes, tapsets = modes0.copy(), tapsets0.copy()
+        chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, sets_i, sets_q, modes=modes, tapsets=tapsets, biquad_nodes=[[lp], [nt]])
+        got = np.empty((ch, ticks * 128), np.int16)
+        r2 = np.random.default_rng(7)
+        for t in range(ticks):
+            if t in (9, 20):
+                for c in (0, 5, 40, 82):
+                    modes[c], tapsets[c] = (int(r2.integers(1, 5)), int(r2.integers(0, 2))) if mixed else (orclib.AM, 0)
+                    chain.set_mode(c, int(modes[c]), int(tapsets[c]))
+            dx, dy = ctx.to_device(x[:, t * 128:(t + 1) * 128]), ctx.array((ch, 128), np.int16)
+            chain.process(dx, dy, 128)
+            got[:, t * 128:(t + 1) * 128] = dy.download()
+            want_name = "chain_q15mb_kernel (block tiles) + both biquad nodes" if fuse else "chain_q15mb_kernel (channel-batched block tiles)"
+            assert chain.info()["kernel"] == want_name, chain.info()["kernel"]
+        outs.append(got)
+    monkeypatch.delenv("MSDR_Q15_NO_FUSE", raising=False)
+    monkeypatch.delenv("MSDR_MB_NW", raising=False)
+    assert np.array_equal(outs[0], outs[1])
+    if not mixed:
+        for c in (0, 3, 7, 8, 41, 82):
+            want = orc.chain_q15(x[c], orclib.AM, sets_i[0], sets_q[0], biquads=[orc.biquad_teensy_new([lp]), orc.biquad_teensy_new([nt])])
+            assert np.array_equal(outs[0][c], want), c
+
+
 def test_block_q15_matches_reference_golden_and_stream_kernel(ctx, golden, monkeypatch):
     """The reference-generated golden chain vectors at block cadence, and the same through the streaming kernel (MSDR_NO_BLOCK=1)."""
     sigs = ["am", "tones", "noise", "full"]

@@ -253,6 +253,46 @@ def test_f32_chain_oscillator_tables_rewritten(ctx, orc, stages, mode):
             assert rel_rms(got[c], want) < TOL, (j, c, rel_rms(got[c], want), chain.info()["kernel"])
 
 
+@pytest.mark.parametrize("arith", ["f32", "q15"])
+def test_chain_many_oscillator_rewrites_inside_one_history(ctx, orc, arith):
+    """More oscillator generations than round 4's four slots inside ONE FIR history (249 taps, calls of 100 - 128 samples), some of them
+    replaced before any sample arrived under them (two rewrites with no call in between: not a generation) -- tests/debug/fuzz_live.py seed
+    5312 case 23466 (five rewrites inside 328 samples, two of them empty, dropped the oldest real generation: 0.26 of the output).  Every
+    sample in the history is mixed with the table of its own time, as in the reference (the mixer sits in front of the FIR state)."""
+    rng = np.random.default_rng(5312)
+    ch, ntaps = 6, (249 if arith == "f32" else 499)         # (the Q15 oracle takes whole 128-sample blocks: a longer history for as many generations)
+    hi, hq = _hilbert_pair(ntaps)
+    tabs = [_q15_nco(128, k) for k in (5, 7, 11, 13, 17, 19, 23, 29, 31, 37)]
+    plan = [128, 100, "osc", 128, "osc", "osc", 100, "osc", "osc", 100, "osc", 32, "osc", 32, "osc", 32, "osc", 64, 128, 128, 128]
+    if arith == "q15":
+        plan = [128, "osc", 128, "osc", "osc", 128, "osc", "osc", 128, "osc", 128, "osc", 128, "osc", 128, 128, 128, 128, 128]
+    if arith == "f32":
+        bq = _f32_biquads(orc, 2)
+        chain = msdr.Chain(ctx, msdr.ARITH_F32, ch, hi, hq, mixer=msdr.MIXER_NCO, mode=orclib.USB, osc_i=tabs[0][0], osc_q=tabs[0][1], biquad_coeffs=bq)
+    else:
+        qi, qq = (np.concatenate([[0], np.round(h * 32768)]).astype(np.int16) for h in (hi, hq))      # (arm_fir_init_q15: an even tap count)
+        qt = [(np.round(a * 32768).astype(np.int16), np.round(b * 32768).astype(np.int16)) for a, b in tabs]
+        chain = msdr.Chain(ctx, msdr.ARITH_Q15, ch, qi, qq, mixer=msdr.MIXER_NCO, mode=orclib.USB, osc_i=qt[0][0], osc_q=qt[0][1])
+    states = {c: {} for c in range(ch)}
+    cur = 0
+    for step, op in enumerate(plan):
+        if op == "osc":
+            cur += 1
+            chain.set_osc(*(tabs[cur] if arith == "f32" else qt[cur]))
+            continue
+        x = rng.integers(-12000, 12001, (ch, op)).astype(np.int16)
+        if arith == "f32":
+            got = run_chain(ctx, chain, x, np.float32)
+            for c in range(ch):
+                want = orc.chain_f32(x[c], orclib.USB, hi, hq, tabs[cur][0], tabs[cur][1], bq, state=states[c])
+                assert rel_rms(got[c], want) < TOL, (step, c, rel_rms(got[c], want), chain.info()["kernel"])
+        else:
+            got = run_chain(ctx, chain, x, np.int16)
+            for c in range(ch):
+                want = orc.chain_q15(x[c], orclib.USB, qi, qq, mixer=1, osc_i=qt[cur][0], osc_q=qt[cur][1], state=states[c])
+                assert np.array_equal(got[c], want), (step, c, chain.info()["kernel"])
+
+
 def test_f32_chain_updates_with_pll_channels(ctx, orc):
     """Row f2 inside the fp32 chain (SYNCAM PLL) rides on an auxiliary chain and a post cascade: both follow a tap change and a
     cascade change, the PLL's state untouched.  (LMS channels are left out here: the filter's leak control takes a decision per

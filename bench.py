@@ -1188,8 +1188,8 @@ def bench_update_all(args, msdr, rank):
     gbs = 4.0 * ch * 128 / (tick_ms * 1e-3) / 1e9
     return {"value": d["Msamples_per_s"], "ms_per_step": round(tick_ms, 5), "dtype": "q15 (int16 data, wrapping int32 accumulate)",
             "config": {"workload": "update_all: %d AM channels x 128 per AudioStream::update_all() tick, %d-tap designer low-pass pair + biquad1_dac + biquad2_dac, %d ticks" % (ch, taps, d["ticks"]),
-                       "kernel": "update_all: d2d copy + chain_q15mb_kernel + biquad_teensy_pipe4_kernel", "graph": d["graph"], "steps_timed": d["ticks"]},
-            "roofline": {"bound": "latency (three launches per tick, the node recursion serial per channel)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "kernel": "update_all: d2d copy + chain_q15mb_kernel with both biquad nodes as its second phase", "graph": d["graph"], "steps_timed": d["ticks"]},
+            "roofline": {"bound": "latency (two launches per tick, the node recursion serial per channel)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None, "kernel_ms": round(tick_ms, 5), "tick_us": round(d["tick_us"], 2),
                          "note_block": "wall time per update_all() tick of the C++ graph runtime, ticks queued back to back (kernel_ms = the same figure: not separated here)"},
             "parity": {"mismatching_samples": float(bad), "tolerance": 0, "samples_checked": int(min(4, ch) * 128),

@@ -166,9 +166,10 @@ int msdr_fir_q15_destroy(msdr_fir_q15 *S);
 /* arm_fir_init_f32 / arm_fir_f32 (prototypes arm_math.h:1182-1202; CMSIS-DSP V1.5.x). Any numTaps >= 1. */
 typedef struct msdr_fir_f32 msdr_fir_f32;
 int msdr_fir_f32_create(msdr_ctx *ctx, uint16_t numTaps, const float32_t *pCoeffs, uint32_t channels, msdr_fir_f32 **out);
-/* (Not capturable into a HIP graph: the 16..~290-tap kernel deals its tiles from one of two counter sets that alternate between
- * launches on the host, so a replayed launch would find its counters spent.  msdr_fir_f32_kernel_name reports the kernel for blocks
- * below 2^31 tiles x channels; beyond that the one-stream-per-wave kernel runs.) */
+/* (The 16..~290-tap kernel deals its tiles from a queue that the launch itself leaves as it found it -- its last wave out re-zeroes the
+ * counters --, so a launch can be replayed; what alternates from call to call is the pair of history buffers, as in the chain: a HIP graph
+ * a caller records over this stage should hold an even number of consecutive calls.  msdr_fir_f32_kernel_name reports the kernel for
+ * blocks below 2^31 tiles x channels; beyond that the one-stream-per-wave kernel runs.) */
 int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, float32_t *d_dst, uint32_t blockSize);
 int msdr_fir_f32_reset(msdr_fir_f32 *S);
 int msdr_fir_f32_set_coeffs(msdr_fir_f32 *S, const float32_t *pCoeffs);   /* as msdr_fir_q15_set_coeffs: state kept, same numTaps */

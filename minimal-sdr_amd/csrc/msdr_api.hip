@@ -771,7 +771,7 @@ struct msdr_fir_f32 : FirInst<float, float> {
     int tr_ns = 0, tr_skip1 = 0;
     // tile queue of fir_f32tq_kernel (msdr_fir_f32tq.hiph): two sets of front counters that alternate between launches, or null
     unsigned *d_tq_ctr = nullptr;
-    int tq_flip = 0, tq_fronts = 32;     // 32 fronts: 24 ... 64 within 1 %, 16 and fewer saturate the counters (profiles/r03/fir_ab.txt)
+    int tq_fronts = 32;     // 32 fronts: 24 ... 64 within 1 %, 16 and fewer saturate the counters (profiles/r03/fir_ab.txt)
     // tiles per draw = 2^shift (round 4): the second .. last tile of a run take their 1 KB halo from the registers that hold the tile before.
     // Runs of 4 / 8: HBM traffic / algorithmic 1.049 -> 1.037 / ~1.02 (the halos that are still fetched all miss L2), a fifth of the loads gone;
     // time -0.5 % only (the kernel sits at the power cap: the clock rises by what the traffic saves), runs of 2 .. 8 alike
@@ -1005,7 +1005,7 @@ extern "C" int msdr_fir_f32_create(msdr_ctx *ctx, uint16_t numTaps, const float3
                         }
             rc = upload(ctx, tb, &S->d_tr_tab);
             S->tr_ns = trs; S->tr_skip1 = (N <= H - 15) ? 1 : 0;
-            if (!rc) rc = dzalloc(ctx, (size_t)2 * kTqMaxFronts * kTqCtrStride, &S->d_tq_ctr);
+            if (!rc) rc = dzalloc(ctx, (size_t)kTqMaxFronts * kTqCtrStride + 16, &S->d_tq_ctr);      // the fronts' counters | the "waves out" word
         }
         if (!rc) rc = fir_f32_upload_header(S);
         if (rc) { msdr_fir_f32_destroy(S); *out = nullptr; return rc; }
@@ -1040,8 +1040,7 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
         const unsigned want = (unsigned)std::min<long long>(2LL * S->ctx->num_cus, ((long long)q.total + 3) / 4);
         q.fronts = (unsigned)std::max(1, std::min<int>(S->tq_fronts, (int)want));
         q.per_front = (q.total + q.fronts - 1) / q.fronts;
-        q.ctr = S->d_tq_ctr + (size_t)S->tq_flip * kTqMaxFronts * kTqCtrStride;
-        q.ctr_next = S->d_tq_ctr + (size_t)(S->tq_flip ^ 1) * kTqMaxFronts * kTqCtrStride;
+        q.ctr = S->d_tq_ctr; q.ctr_next = nullptr; q.done = S->d_tq_ctr + (size_t)kTqMaxFronts * kTqCtrStride;      // (the kernel leaves both as it found them: zero)
         q.all_aligned = ((blockSize & 3u) == 0 && (reinterpret_cast<uintptr_t>(d_src) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_dst) & 15) == 0) ? 1 : 0;
         const unsigned grid = std::max(want, q.fronts);
         // runs of consecutive tiles per draw (the halo of the second .. last comes from registers): as long as every wave still gets >= 64 runs
@@ -1053,7 +1052,7 @@ extern "C" int msdr_fir_f32_process(msdr_fir_f32 *S, const float32_t *d_src, flo
         { KernelTimer kt(S->ctx);
           if (launch_fir_f32tq(S->ctx->stream, S->tr_ns, S->tr_skip1, grid, lds, q) == hipErrorInvalidValue) return fail(MSDR_STATUS_ARGUMENT_ERROR, "fir_f32tq: step count not built"); }
         if (int rc = launch_check("fir_f32tq_kernel")) return rc;
-        S->tq_flip ^= 1; S->last_launch = 1;
+        S->last_launch = 1;
         hipLaunchKernelGGL((history_kernel<float>), dim3(grid_1d((long long)S->channels * S->hist_len)), dim3(256), 0, S->ctx->stream,
                            d_src, (const float *)S->d_hist[S->cur], S->d_hist[S->cur ^ 1], (long long)blockSize, (int)S->hist_len, (int)S->channels);
         if (int rc = launch_check("history_kernel")) return rc;
@@ -1912,6 +1911,12 @@ struct msdr_chain {
     msdr_ctx *ctx;
     ChainCfgStore store;
     double own_d_bound, own_sig_bound;   // what this chain's own tap sets can leave in the cascade's state (floors for a rebuilt chain's table scales)
+    // ... and the floors THIS chain was built over, for as long as no sample has been processed since (floor_gen == gen): the state it carries is
+    // still its predecessor's, so a second live update in a row must size its tables for that predecessor too (tests/debug/fuzz_live.py seed
+    // 5202 case 44155: taps 20 x smaller, then a cascade rewrite, no call in between -- the second rebuild scaled for the small taps only and the
+    // state of the large ones went through fp16 out of range: 1.1e-3 on the SSB channels' next block)
+    double floor_d = 0.0, floor_sig = 0.0;
+    uint64_t floor_gen = ~0ull;
     // msdr_chain_set_osc: the tables that were in force when the samples still in the FIR history arrived, oldest first.  While any is
     // pending the chain runs chain_kernel<Arith>, which mixes every history sample with the table of its own time.
     struct OscPending { void *d_tab; long long elapsed; };
@@ -3773,6 +3778,8 @@ static int chain_rebuild(msdr_chain *c, const ChainCfgStore &edited, void **stea
     edited.view(&cfg, c->h_mode, c->h_tapset);
     msdr_chain *n = nullptr;
     g_chain_floor_d = c->own_d_bound; g_chain_floor_sig = c->own_sig_bound;
+    if (c->floor_gen == c->gen) { g_chain_floor_d = std::max(g_chain_floor_d, c->floor_d); g_chain_floor_sig = std::max(g_chain_floor_sig, c->floor_sig); }
+    const double used_d = g_chain_floor_d, used_sig = g_chain_floor_sig;
     const int rc = msdr_chain_create(c->ctx, &cfg, &n);
     g_chain_floor_d = 0.0; g_chain_floor_sig = 0.0;
     if (rc) return rc;
@@ -3804,6 +3811,7 @@ static int chain_rebuild(msdr_chain *c, const ChainCfgStore &edited, void **stea
     n->post_mode_gen = 0; n->post_anr_gen = 0;
     // bookkeeping of the stream
     n->gen = c->gen; n->dh_cache = c->dh_cache; n->dh_gen = c->dh_gen;
+    n->floor_d = used_d; n->floor_sig = used_sig; n->floor_gen = c->gen;
     n->timing = c->timing; n->events.swap(c->events); n->timed_ms = c->timed_ms; n->timed_launches = c->timed_launches;
     n->info = c->info;
     n->osc_pending.swap(c->osc_pending); n->force_generic = c->force_generic;

@@ -293,6 +293,67 @@ def test_chain_many_oscillator_rewrites_inside_one_history(ctx, orc, arith):
                 assert np.array_equal(got[c], want), (step, c, chain.info()["kernel"])
 
 
+@pytest.mark.parametrize("scale", [0.05, 20.0])
+@pytest.mark.parametrize("second", ["biquad", "mode", "taps"])
+def test_f32_chain_two_updates_in_a_row_keep_the_first_chain_s_scale(ctx, orc, scale, second):
+    """Two live updates with no call in between, the first one a tap set with 20 x less (or more) gain: the state the chain carries is still the
+    ORIGINAL chain's, so the tables of the second rebuild must be scaled for that one too -- its cascade state and numerator history pass
+    through fp16 at the table's scale.  tests/debug/fuzz_live.py seed 5202 case 44155 (taps x 0.05, then a cascade rewrite): the second
+    rebuild sized its tables for the small taps only: 1.1e-3 on the SSB channels' next block."""
+    rng = np.random.default_rng(5202)
+    ntaps = 230
+    hi, hq = _hilbert_pair(ntaps)
+    bq = _f32_biquads(orc, 2)
+    modes = np.array([orclib.AM, orclib.LSB, orclib.USB, orclib.CW], np.int32)
+    oi, oq = _q15_nco(8, 1)
+    chain = msdr.Chain(ctx, msdr.ARITH_F32, 4, hi, hq, mixer=msdr.MIXER_NCO, modes=modes, osc_i=oi, osc_q=oq, biquad_coeffs=bq)
+    states = {c: {} for c in range(4)}
+
+    def run(n, tag):
+        x = rng.integers(-20000, 20001, (4, n)).astype(np.int16)
+        got = run_chain(ctx, chain, x, np.float32)
+        for c in range(4):
+            want = orc.chain_f32(x[c], int(modes[c]), hi, hq, oi, oq, bq, state=states[c])
+            assert rel_rms(got[c], want) < TOL, (tag, c, rel_rms(got[c], want), chain.info()["kernel"])
+    run(2432, "before")
+    h2i, h2q = _hilbert_pair(ntaps, fc=1700.0, bw=2300.0)
+    hi, hq = (h2i * scale).astype(np.float32), (h2q * scale).astype(np.float32)
+    chain.set_taps(0, hi, hq)
+    if second == "biquad":
+        bq = bq.copy()
+        c30 = orc.biquad_design(orclib.BQ_LOWPASS, np.float32(4800.0 * CORR), 0.8).astype(np.float64) / 2 ** 30
+        bq[1] = [c30[0], c30[1], c30[2], -c30[3], -c30[4]]
+        chain.set_biquad_coeffs(bq)
+    elif second == "mode":
+        modes[1], modes[2] = modes[2], modes[1]
+        chain.set_mode(1, int(modes[1]), 0)
+        chain.set_mode(2, int(modes[2]), 0)
+    else:
+        hi, hq = (h2q * scale).astype(np.float32), (h2i * scale).astype(np.float32)
+        chain.set_taps(0, hi, hq)
+    run(128, "first block")
+    run(1024, "after")
+
+
+@pytest.mark.parametrize("seed,case", [(5202, 44155), (5312, 23466)])
+def test_the_fuzzer_s_findings_of_round_5_stay_fixed(seed, case):
+    """The two defects tests/debug/fuzz_live.py found in round 5, replayed draw for draw (a child process: the fuzzer is a script): seed 5202
+    case 44155 -- taps x 0.05, then a cascade rewrite, no call in between (the second rebuild's table scale forgot the first chain's state:
+    1.1e-3) --, seed 5312 case 23466 -- five oscillator rewrites inside one FIR history, two of them empty (the oldest real generation dropped:
+    0.26).  Both were found on libraries that passed every shaped test of this file, the one above included."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if seed == 5312:
+        env["FUZZ_BLOCK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "debug", "fuzz_live.py"), "60", str(seed), str(case)], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "MISMATCH" not in r.stdout and " 0 mismatches" in r.stdout, r.stdout[-2000:]
+
+
 def test_f32_chain_updates_with_pll_channels(ctx, orc):
     """Row f2 inside the fp32 chain (SYNCAM PLL) rides on an auxiliary chain and a post cascade: both follow a tap change and a
     cascade change, the PLL's state untouched.  (LMS channels are left out here: the filter's leak control takes a decision per

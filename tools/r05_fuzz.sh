@@ -15,3 +15,12 @@ if [ "${1:-a}" = "e" ]; then
   export FUZZ_BLOCK=1
   run fuzz_live 300 ${SEED1:-5301}; run fuzz_live 300 ${SEED2:-5302}
 fi
+# after the round's two live-update fixes: the seed that found the second defect again, and fresh ones (plain and block cadence)
+if [ "${1:-a}" = "f" ]; then
+  run fuzz_live 300 5202; run fuzz_live 300 5203
+  export FUZZ_BLOCK=1
+  run fuzz_live 300 5331
+fi
+if [ "${1:-a}" = "g" ]; then      # the FIR stage's self-resetting tile queue, the kernels and the retune paths once more on the last library
+  run fuzz_fir_f32 200 5113; run fuzz_kernels 280 5211; run fuzz_retune 150 5204
+fi

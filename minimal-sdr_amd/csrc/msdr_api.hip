@@ -3771,7 +3771,12 @@ __global__ void hist_resize_kernel(const int16_t *__restrict__ src, int16_t *__r
     }
 }
 
-static int chain_rebuild(msdr_chain *c, const ChainCfgStore &edited, void **steal_osc = nullptr)
+// extra_floor_d / extra_floor_sig: what the caller KNOWS it will hand the rebuilt chain (numerator history / section states, in units of
+// in_scale): msdr_chain_set_biquad_coeffs converts the running cascade's state into the new cascade's basis, and neither chain's own bounds
+// say how large that comes out (tests/debug/fuzz_live.py seed 5342 case 38296: a resonant cascade that ran in CMSIS order behind the kernel,
+// rewritten to one that runs inside it -- the old chain had no bounds at all, the new tables were scaled for the new cascade's gains, and
+// the converted state left fp16's range: 23 x the output on the next call, decaying over the two after it)
+static int chain_rebuild(msdr_chain *c, const ChainCfgStore &edited, void **steal_osc = nullptr, double extra_floor_d = 0.0, double extra_floor_sig = 0.0)
 {
     HIP_TRY(hipStreamSynchronize(c->ctx->stream));
     msdr_chain_config cfg;
@@ -3779,6 +3784,7 @@ static int chain_rebuild(msdr_chain *c, const ChainCfgStore &edited, void **stea
     msdr_chain *n = nullptr;
     g_chain_floor_d = c->own_d_bound; g_chain_floor_sig = c->own_sig_bound;
     if (c->floor_gen == c->gen) { g_chain_floor_d = std::max(g_chain_floor_d, c->floor_d); g_chain_floor_sig = std::max(g_chain_floor_sig, c->floor_sig); }
+    g_chain_floor_d = std::max(g_chain_floor_d, extra_floor_d); g_chain_floor_sig = std::max(g_chain_floor_sig, extra_floor_sig);
     const double used_d = g_chain_floor_d, used_sig = g_chain_floor_sig;
     const int rc = msdr_chain_create(c->ctx, &cfg, &n);
     g_chain_floor_d = 0.0; g_chain_floor_sig = 0.0;
@@ -3977,9 +3983,23 @@ extern "C" int msdr_chain_set_biquad_coeffs(msdr_chain *c, const float32_t *coef
     if (!new_seq && !br.ok_from) return fail(MSDR_STATUS_ARGUMENT_ERROR, "no block-parallel state reproduces the CMSIS state under the new coefficients");
     ChainCfgStore ed = c->store;
     ed.bq.assign(coeffs, coeffs + 5 * S);
+    // what the rebuilt chain will be handed, measured: the section states in the new cascade's basis and the numerator history, over all channels
+    double floor_d = 0.0, floor_sig = 0.0;
+    if (!new_seq) {
+        float w[16];
+        for (uint32_t ch = 0; ch < c->channels; ch++) {
+            br.cmsis_to_lib(Y.data() + (size_t)ch * ny, D.data() + (size_t)ch * 8, w);
+            for (int k = 0; k < 2 * S; k++) {
+                if (std::isfinite(w[k])) floor_sig = std::max(floor_sig, (double)std::fabs(w[k]));
+                floor_d = std::max(floor_d, std::fabs(D[(size_t)ch * 8 + k]));
+            }
+        }
+        const double inv = 1.5 / std::max((double)c->in_scale, 1e-300);      // (the bounds are kept in units of in_scale; half again for the first block's growth)
+        floor_d *= inv; floor_sig *= inv;
+    }
     msdr_biquad_df1_f32 *old_seq = c->seq_bq;          // (chain_rebuild would swap the old object in: the new one must stay)
     c->seq_bq = nullptr;
-    const int rrc = chain_rebuild(c, ed);
+    const int rrc = chain_rebuild(c, ed, nullptr, floor_d, floor_sig);
     if (rrc) { c->seq_bq = old_seq; return rrc; }
     if (old_seq) msdr_biquad_df1_f32_destroy(old_seq);
     if (hist.size() != (size_t)c->channels * c->hist_len) {      // (the history length follows the cascade's place: read the carried-over copy)

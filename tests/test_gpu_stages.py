@@ -584,3 +584,55 @@ def test_fir_f32_tile_queue_runs_of_tiles(ctx, orc, shift, monkeypatch):
         t = truth[:, :full].reshape(ch, -1, 1024)
         per_tile = np.sqrt((d ** 2).sum(axis=2) / (t ** 2).sum(axis=2))
         assert per_tile.max() < 3e-6, (ntaps, ch, np.unravel_index(int(per_tile.argmax()), per_tile.shape), float(per_tile.max()))
+
+
+def test_fir_f32_stage_replays_from_a_hip_graph(ctx, orc):
+    """Round 5: fir_f32tq_kernel leaves its tile queue as it found it (its last wave out re-zeroes the counters; rounds 3 - 4 alternated two
+    counter sets on the host, so a replayed launch found its counters spent -- the review's weak point 8).  Two consecutive
+    msdr_fir_f32_process calls (the history buffers alternate: an even number) captured on the context's stream into ONE HIP graph, replayed
+    five times over fresh input: ten blocks of one continuing stream, every output against a float64 convolution."""
+    import ctypes as C
+    from scipy.signal import fftconvolve
+    hip = C.CDLL("libamdhip64.so")
+    rng = np.random.default_rng(58)
+    ntaps, ch, m = 256, 40, 4096
+    h = (rng.standard_normal(ntaps) * np.hanning(ntaps + 2)[1:-1]).astype(np.float32)
+    fir = msdr.FirF32(ctx, h, ch)
+    assert fir.kernel_name().startswith("fir_f32tq_kernel"), fir.kernel_name()
+    reps = 5
+    x = rng.uniform(-8000, 8000, (ch, (2 + 2 * reps) * m)).astype(np.float32)
+    dx = [ctx.array((ch, m), np.float32) for _ in range(2)]
+    dy = [ctx.array((ch, m), np.float32) for _ in range(2)]
+    got = np.empty_like(x)
+    o = 0
+    for k in range(2):                                             # two direct calls first (nothing is allocated lazily inside the capture)
+        dx[k].upload(x[:, o:o + m]); fir.process(dx[k], dy[k], m); got[:, o:o + m] = dy[k].download(); o += m
+    stream = C.c_void_p(ctx.stream())
+    graph, gexec = C.c_void_p(), C.c_void_p()
+    assert hip.hipStreamBeginCapture(stream, C.c_int(2)) == 0      # hipStreamCaptureModeRelaxed
+    try:
+        for k in range(2):
+            fir.process(dx[k], dy[k], m)
+    finally:
+        rc = hip.hipStreamEndCapture(stream, C.byref(graph))
+    assert rc == 0 and graph.value
+    assert hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, C.c_size_t(0)) == 0
+    try:
+        for _ in range(reps):
+            for k in range(2):
+                dx[k].upload(x[:, o + k * m:o + (k + 1) * m])
+                dy[k].upload(np.full((ch, m), np.nan, np.float32))
+            assert hip.hipGraphLaunch(gexec, stream) == 0
+            for k in range(2):
+                got[:, o:o + m] = dy[k].download(); o += m
+    finally:
+        hip.hipGraphExecDestroy(gexec); hip.hipGraphDestroy(graph)
+    assert not np.isnan(got).any()
+    truth = fftconvolve(x.astype(np.float64), h.astype(np.float64)[::-1][None, :], axes=1)[:, :x.shape[1]]
+    err = np.sqrt(((got - truth) ** 2).sum(axis=1) / (truth ** 2).sum(axis=1))
+    assert err.max() < 1e-6, (int(err.argmax()), float(err.max()))
+    # ... and the stage goes on from where the graph left it, by direct calls
+    x2 = rng.uniform(-8000, 8000, (ch, m)).astype(np.float32)
+    dx[0].upload(x2); fir.process(dx[0], dy[0], m)
+    t2 = fftconvolve(np.concatenate([x, x2], axis=1).astype(np.float64), h.astype(np.float64)[::-1][None, :], axes=1)[:, x.shape[1]:x.shape[1] + m]
+    assert np.sqrt(((dy[0].download() - t2) ** 2).sum() / (t2 ** 2).sum()) < 1e-6

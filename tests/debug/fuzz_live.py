@@ -96,7 +96,7 @@ while time.time() < t_end:
     ok = True
     for j in range(ncall):
         if j:
-            for _ in range(int(rng.integers(1, 3))):
+            for _ in range(int(rng.integers(1, 5 if os.environ.get("FUZZ_OPS4") else 3))):      # (FUZZ_OPS4=1: up to four updates in a row)
                 op = int(rng.integers(0, 6))
                 if op == 0:
                     ts = int(rng.integers(0, nsets))

@@ -24,3 +24,6 @@ fi
 if [ "${1:-a}" = "g" ]; then      # the FIR stage's self-resetting tile queue, the kernels and the retune paths once more on the last library
   run fuzz_fir_f32 200 5113; run fuzz_kernels 280 5211; run fuzz_retune 150 5204
 fi
+if [ "${1:-a}" = "h" ]; then      # the retune / truth / stage fuzzers once more on the round's last library
+  run fuzz_retune 150 5214; run fuzz_retune_q15 150 5215; run fuzz_f32_truth 240 5216; run fuzz_stage_df1 100 5217
+fi

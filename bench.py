@@ -713,6 +713,14 @@ def bench_fir_stage(args, torch, msdr, ctx, dev, rank, world, dist, do_cpu):
 def profile_kernel_name(path):
     """The library kernel a committed profile summary was taken on: its `dominant kernel:` line (tools/prof_summary.py, round 3 on)
     or, in older summaries, the first msdr:: row of the kernel-stats table.  Returns the name without template arguments."""
+    # the kernel the COUNTER passes were taken on, where the summary names it (the row under "FETCH_SIZE counter:"): in a record whose
+    # step runs other kernels behind the chain kernel (q15_c3: the biquad nodes take longer than the demodulator) the kernel with the most
+    # time is not the one the traffic figure belongs to
+    prev = ""
+    for line in open(path):
+        if prev.startswith("FETCH_SIZE counter:") and "msdr::" in line:
+            return line.split("msdr::", 1)[1].split("<")[0].split("(")[0].split()[0]
+        prev = line
     for line in open(path):
         if line.startswith("dominant kernel:"):
             return line.split(":", 1)[1].strip().split("<")[0].replace("void ", "").replace("msdr::", "")

@@ -1981,6 +1981,8 @@ struct msdr_chain {
     struct Summary { uint64_t mode_gen = 0, anr_gen = 0; bool any_ssb = false, any_env = false, any_syncam = false, qm_sets_ok = true, any_anr = false; } sum;
     bool dry_run = false;                // msdr_chain_graph_create: msdr_chain_process prepares a block-cadence call (tables, caches) and returns before its launches
     bool block_off = false;              // MSDR_NO_BLOCK=1 at create time: keep the wave-stream kernels at every call length (A/B runs, tests)
+    bool no_fuse = false;                // MSDR_Q15_NO_FUSE=1 at create time: the biquad nodes as a kernel behind chain_q15mb_kernel, not its second phase
+    int blk_force = -1;                  // MSDR_BIQUAD_BLK at create time (0: never biquad_teensy_blk_kernel, 1: always where it applies; -1: the host's rule)
     std::vector<std::vector<float>> h_coef_i, h_coef_q;   // host copies for msdr_chain_set_mode
     std::vector<double> h_osc, h_cnum;                    // oscillator pairs {cos, sin}; combined numerator
     struct DHist { double v[8]; };
@@ -2137,6 +2139,8 @@ static int chain_create_impl(msdr_ctx *ctx, const msdr_chain_config *cfg, msdr_c
     c->cur = 0; c->phase = 0; c->timing = false; c->timed_ms = 0; c->timed_launches = 0;
     c->gen = 1; c->dh_cache.resize(c->channels); c->dh_gen.assign(c->channels, 0);
     c->block_off = getenv("MSDR_NO_BLOCK") != nullptr;
+    c->no_fuse = getenv("MSDR_Q15_NO_FUSE") != nullptr;
+    c->blk_force = getenv("MSDR_BIQUAD_BLK") ? atoi(getenv("MSDR_BIQUAD_BLK")) : -1;
     c->flags = cfg->flags; c->mfw_nw = 0; c->mfw_waves_per_cu = 0; c->d_bq_state_alt = nullptr; c->d_mw_iir = nullptr; c->d_units = nullptr; c->units_cap = 0;
     c->mode_gen = 1; c->units_mode_gen = 0; c->units_nseg = 0; c->units_wgs = 0; c->units_wgs_ssb = 0; c->mfw_ssb_fold = false; c->mfw_am_fold = false; c->units_tiles = -1;
     c->part_nseg[0] = c->part_nseg[1] = 1; c->part_seg_len[0] = c->part_seg_len[1] = 0;
@@ -3371,9 +3375,9 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
         grid = 0;
         // the two biquad nodes as the kernel's second phase: the reference's configuration (one stage per node, nothing between the
         // demodulator and the nodes), one 128-sample block, and every launch of this call with one tile per wave on three or more waves
-        // (small batches: up to 16 384 channels of one flavour on this part); MSDR_Q15_NO_FUSE=1: the node kernel behind it as before
+        // (small batches: up to 16 384 channels of one flavour on this part); MSDR_Q15_NO_FUSE=1 at create time: the node kernel behind it as before
         nodes_fused = c->nnodes == 2 && c->nodes[0]->max_stage == 0 && c->nodes[1]->max_stage == 0 && n_samples == 128 && !pll_active &&
-                      !(c->anr && (c->d_anr_on || c->anr_all > 0)) && !getenv("MSDR_Q15_NO_FUSE");
+                      !(c->anr && (c->d_anr_on || c->anr_all > 0)) && !c->no_fuse;
         for (int part = 0; part < 2 && nodes_fused; part++) {
             const msdr_chain::BlockPart &bp = c->bpart[part];
             if (bp.wgs && (bp.tpw != 1 || bp.nw < 3 || qb_nodes_lds_bytes(c->qm_halo, 128, c->qm_bsteps, (int)bp.nw) > 160 * 1024)) nodes_fused = false;
@@ -3460,9 +3464,8 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
             // one stage per node (the reference's configuration): the recursions alone on two waves, the input products element-wise on the others
             // (one 128-sample block, the reference's cadence: the pipeline over sub-slabs inside the block, while its 16-channel workgroups find a
             //  CU each -- 4096 channels: 15.1 -> 13.2 us per tick; at 8192 the slab kernel is ahead again, 16.6 vs 17.3, tools/r05_nodes_x.sh;
-            //  MSDR_BIQUAD_BLK=0 / 1 overrides)
-            const char *blk_env = getenv("MSDR_BIQUAD_BLK");
-            const int blk_force = blk_env ? atoi(blk_env) : -1;
+            //  MSDR_BIQUAD_BLK=0 / 1 at create time overrides)
+            const int blk_force = c->blk_force;
             if (n_samples == 128 && (c->channels & 15u) == 0 && (blk_force == 1 || (blk_force < 0 && c->channels / kTqbCh <= (uint32_t)c->ctx->num_cus)))
                 hipLaunchKernelGGL(biquad_teensy_blk_kernel, dim3(c->channels / kTqbCh), dim3(kTqbThreads), tqb_lds_bytes(), c->ctx->stream, (short *)d_audio,
                                    c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels);

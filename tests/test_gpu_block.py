@@ -349,6 +349,7 @@ def test_block_q15_nodes_sub_slab_pipeline_bit_exact(ctx, orc, golden, monkeypat
     x[3] = -32768
     x[5] = 32767
     outs = []
+    monkeypatch.setenv("MSDR_Q15_NO_FUSE", "1")                 # (the node kernels on their own: where the chain kernel takes the nodes in, this test would compare it with itself)
     for force in (None, "0"):
         if force is None:
             monkeypatch.delenv("MSDR_BIQUAD_BLK", raising=False)
@@ -358,6 +359,7 @@ def test_block_q15_nodes_sub_slab_pipeline_bit_exact(ctx, orc, golden, monkeypat
         outs.append(run_chain(ctx, chain, x, np.int16, 128))
         assert _is_qblock(chain), chain.info()["kernel"]
     monkeypatch.delenv("MSDR_BIQUAD_BLK", raising=False)
+    monkeypatch.delenv("MSDR_Q15_NO_FUSE", raising=False)
     assert np.array_equal(outs[0], outs[1])
     for c in sorted(set([0, 3, 5, 15, ch - 1, ch // 2])):
         want = orc.chain_q15(x[c], orclib.AM, taps, taps, biquads=[orc.biquad_teensy_new([lp]), orc.biquad_teensy_new([nt])])

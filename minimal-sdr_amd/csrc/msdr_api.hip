@@ -761,6 +761,11 @@ struct msdr_fir_q15 : FirInst<int16_t, int32_t> {
     char *d_qm_tab = nullptr;
     int *d_qm_order = nullptr;
     int qm_stride = 0, qm_halo = 0, qm_bsteps = 0;
+    // block cadence (chain_q15mb_kernel<3>: calls of 32 .. 512 samples, the reference's 128 among them): the tile table of the last block
+    // length seen (identity order: one tap set), waves per workgroup, tiles per wave
+    int *d_btiles = nullptr;
+    size_t btiles_cap = 0;
+    uint32_t bt_n = 0, bt_wgs = 0, bt_nw = 0, bt_tpw = 0;
 };
 struct msdr_fir_f32 : FirInst<float, float> {
     // matrix-core path (msdr_fir_f32mf.hiph): header + split-fp16 Toeplitz fragments, or null (then fir_kernel<FirF32> runs)
@@ -875,8 +880,63 @@ extern "C" int msdr_fir_q15_create(msdr_ctx *ctx, uint16_t numTaps, const q15_t 
             if (!rc) rc = upload(ctx, order, &S->d_qm_order);
             if (rc) { msdr_fir_q15_destroy(S); *out = nullptr; return rc; }
             S->qm_stride = T.stride; S->qm_halo = T.halo; S->qm_bsteps = T.bsteps;
+            // the history in the matrix-core window's length (the block kernel stages whole windows of qm_halo + n samples and writes the next
+            // history itself; the long-call kernel takes any length >= numTaps - 1)
+            if ((uint32_t)T.halo > S->hist_len) {
+                hipFree(S->d_hist[0]); hipFree(S->d_hist[1]); S->d_hist[0] = S->d_hist[1] = nullptr;
+                S->hist_len = (uint32_t)T.halo;
+                rc = dzalloc(ctx, (size_t)channels * S->hist_len, &S->d_hist[0]);
+                if (!rc) rc = dzalloc(ctx, (size_t)channels * S->hist_len, &S->d_hist[1]);
+                if (rc) { msdr_fir_q15_destroy(S); *out = nullptr; return rc; }
+            }
         }
     }
+    return 0;
+}
+// the block-cadence tile table of a FIR stage: every channel on the one tap set, in channel order (the rules of chain_block_tiles)
+static int fir_q15_block_tiles(msdr_fir_q15 *S, int n)
+{
+    if (S->bt_n == (uint32_t)n && S->d_btiles) return 0;
+    const int cpt = mb_cpt(n);
+    int fill = cpt;
+    auto tiles_at = [&](int f) { return ((long long)S->channels + f - 1) / f; };
+    while (fill > 1 && tiles_at(fill) * 2 <= (long long)S->ctx->num_cus * 4) fill >>= 1;
+    const long long tiles = tiles_at(fill);
+    long long best_cost = -1;
+    uint32_t nw = 1, tpw = 1;
+    for (int w = 1; w <= 8; w++) {
+        long long t = (tiles + (long long)S->ctx->num_cus * w - 1) / ((long long)S->ctx->num_cus * w);
+        t = std::max<long long>(1, std::min<long long>(t, kMbMaxTableInts / cpt));
+        if (qb_lds_bytes(S->qm_halo, n, S->qm_bsteps, w, (int)t) > 160 * 1024) break;
+        const long long cost = t * (w <= 4 ? 2 : 3);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; nw = (uint32_t)w; tpw = (uint32_t)t; }
+    }
+    if (qb_lds_bytes(S->qm_halo, n, S->qm_bsteps, (int)nw, (int)tpw) > 160 * 1024) return -1;      // not even one wave with one tile: the caller takes the long-call kernel
+    const size_t per_wg = (size_t)nw * tpw;
+    std::vector<int> tab;
+    uint32_t wgs = 0;
+    for (size_t t0 = 0; t0 < (size_t)tiles; t0 += per_wg, wgs++) {
+        tab.push_back(0); tab.push_back(0); tab.push_back(0); tab.push_back(0);       // kMbRecHdrInts: {tap set 0, ...}
+        const size_t base = tab.size();
+        tab.resize(base + per_wg * cpt, -1);
+        const size_t cnt = std::min(per_wg, (size_t)tiles - t0);
+        for (size_t t = 0; t < cnt; t++) {
+            const size_t slot = (t % nw) * tpw + t / nw;
+            for (int k = 0; k < fill; k++) {
+                const size_t idx = (t0 + t) * fill + k;
+                if (idx < S->channels) tab[base + slot * cpt + k] = (int)idx;
+            }
+        }
+    }
+    if (tab.size() > S->btiles_cap) {
+        HIP_TRY(hipStreamSynchronize(S->ctx->stream));
+        hipFree(S->d_btiles); S->d_btiles = nullptr; S->btiles_cap = 0;
+        if (int rc = dzalloc(S->ctx, tab.size(), &S->d_btiles)) return rc;
+        S->btiles_cap = tab.size();
+    }
+    HIP_TRY(hipMemcpyAsync(S->d_btiles, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, S->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(S->ctx->stream));
+    S->bt_n = (uint32_t)n; S->bt_wgs = wgs; S->bt_nw = nw; S->bt_tpw = tpw;
     return 0;
 }
 extern "C" int msdr_fir_q15_process(msdr_fir_q15 *S, const q15_t *d_src, q15_t *d_dst, uint32_t blockSize)
@@ -892,6 +952,23 @@ extern "C" int msdr_fir_q15_process(msdr_fir_q15 *S, const q15_t *d_src, q15_t *
     q.x = d_src; q.out = d_dst; q.hist_in = S->d_hist[S->cur]; q.n = (long long)blockSize; q.channels = (int)S->channels;
     q.hist_len = (int)S->hist_len; q.ntaps_pad = (int)S->ntaps_pad; q.mixer = MSDR_MIXER_FS4; q.phase0 = 0;
     q.mf_tab = S->d_qm_tab; q.mf_stride = S->qm_stride; q.mf_halo = S->qm_halo; q.mf_bsteps = S->qm_bsteps; q.mf_units = S->d_qm_order;
+    // the reference's cadence -- arm_fir_fast_q15(&FIR_I, I_buffer, I_FIR_out, AUDIO_BLOCK_SAMPLES), Minimal-SDR.ino:574-575 --: channel-batched
+    // tiles, ONE kernel that also writes the next history (msdr_chain_q15mb.hiph, flavour 3); MSDR_NO_BLOCK=1 keeps the long-call kernel
+    if (mb_n_ok((long long)blockSize) && (int)S->hist_len == S->qm_halo && !getenv("MSDR_NO_BLOCK") &&
+        ((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(d_dst)) & 15) == 0 &&
+        (unsigned long long)S->channels * std::max<unsigned long long>(S->hist_len, blockSize) * 2ull < (1ull << 32)) {
+        const int brc = fir_q15_block_tiles(S, (int)blockSize);
+        if (brc > 0) return brc;
+        if (brc == 0) {
+            q.hist_out = S->d_hist[S->cur ^ 1];
+            q.mf_units = S->d_btiles; q.mf_nw = (int)S->bt_nw; q.nseg = (int)S->bt_tpw;
+            const size_t lds = qb_lds_bytes(S->qm_halo, (int)blockSize, S->qm_bsteps, (int)S->bt_nw, (int)S->bt_tpw);
+            { KernelTimer kt(S->ctx); (void)launch_chain_q15mb(S->ctx->stream, 3, false, S->bt_wgs, S->bt_nw * 64, lds, q); }
+            if (int rc = launch_check("chain_q15mb_kernel<3>")) return rc;
+            S->cur ^= 1;
+            return 0;
+        }
+    }
     const long long qtiles = ((long long)blockSize + kQmTile - 1) / kQmTile;
     long long qseg = (8192 + S->channels - 1) / S->channels;                       // two rounds of 16 waves per CU, >= two tiles per segment
     qseg = std::max<long long>(1, std::min<long long>(qseg, std::max<long long>(1, qtiles / 2)));
@@ -913,7 +990,7 @@ extern "C" int msdr_fir_q15_process(msdr_fir_q15 *S, const q15_t *d_src, q15_t *
 extern "C" int msdr_fir_q15_reset(msdr_fir_q15 *S) { return fir_reset(S); }
 extern "C" int msdr_fir_q15_destroy(msdr_fir_q15 *S)
 {
-    if (S) { hipFree(S->d_qm_tab); hipFree(S->d_qm_order); }
+    if (S) { hipFree(S->d_qm_tab); hipFree(S->d_qm_order); hipFree(S->d_btiles); }
     return fir_destroy(S);
 }
 // New coefficients under a running filter (the reference: the array behind S->pCoeffs rewritten in place, UI.cpp:337-345 +

@@ -11,7 +11,7 @@
 namespace msdr {
 // chain_mfb_kernel<S, AM> (msdr_chain_mfb.hiph): stages = 0, 1, 2; am = the workgroups' tables are envelope tables.  Returns the HIP error of the launch.
 hipError_t launch_chain_mfb(hipStream_t stream, int stages, bool am, unsigned grid, unsigned block, size_t lds_bytes, const ChainParams &p);
-// chain_q15mb_kernel<FLAVOUR> (msdr_chain_q15mb.hiph): 0 = LSB / USB channels, 1 = envelope (sqrtf), 2 = envelope (arm_sqrt_q31)
+// chain_q15mb_kernel<FLAVOUR> (msdr_chain_q15mb.hiph): 0 = LSB / USB channels, 1 = envelope (sqrtf), 2 = envelope (arm_sqrt_q31), 3 = the arm_fir_fast_q15 stage alone
 // nodes: the two AudioFilterBiquad nodes as the kernel's second phase (p.bq_state / p.bq_state_out = their records; one tile per wave, >= 3 waves, n = 128)
 hipError_t launch_chain_q15mb(hipStream_t stream, int flavour, bool nodes, unsigned grid, unsigned block, size_t lds_bytes, const ChainParams &p);
 // ---- msdr_chain_stream.hip ----

@@ -56,6 +56,7 @@ hipError_t launch_chain_q15mb(hipStream_t stream, int flavour, bool nodes, unsig
     case 0: hipLaunchKernelGGL((chain_q15mb_kernel<0>), dim3(grid), dim3(block), lds, stream, p); break;
     case 1: hipLaunchKernelGGL((chain_q15mb_kernel<1>), dim3(grid), dim3(block), lds, stream, p); break;
     case 2: hipLaunchKernelGGL((chain_q15mb_kernel<2>), dim3(grid), dim3(block), lds, stream, p); break;
+    case 3: hipLaunchKernelGGL((chain_q15mb_kernel<3>), dim3(grid), dim3(block), lds, stream, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -80,7 +80,7 @@ def test_block_cadence_kernels_have_no_scratch_traffic(tmp_path):
     tile's window behind the matrix products: a spill there has the same cost as in the wave-stream kernels (a scratch reload waits for
     the prefetch in front of it).  Every instantiation, no scratch instruction."""
     text = "\n".join(subprocess.run([OBJDUMP, "-d", co], check=True, stdout=subprocess.PIPE, text=True).stdout for co in code_object(str(tmp_path)))
-    for needle, count in (("chain_mfb_kernel", 6), ("chain_q15mb_kernel", 6)):          # (Q15: three flavours, each with and without the biquad nodes as a second phase)
+    for needle, count in (("chain_mfb_kernel", 6), ("chain_q15mb_kernel", 7)):          # (Q15: three chain flavours, each with and without the biquad nodes as a second phase, and the FIR stage)
         kernels = kernels_of(text, needle)
         assert len(kernels) == count, (needle, sorted(kernels))
         for name, ins in kernels.items():

@@ -636,3 +636,40 @@ def test_fir_f32_stage_replays_from_a_hip_graph(ctx, orc):
     dx[0].upload(x2); fir.process(dx[0], dy[0], m)
     t2 = fftconvolve(np.concatenate([x, x2], axis=1).astype(np.float64), h.astype(np.float64)[::-1][None, :], axes=1)[:, x.shape[1]:x.shape[1] + m]
     assert np.sqrt(((dy[0].download() - t2) ** 2).sum() / (t2 ** 2).sum()) < 1e-6
+
+
+@pytest.mark.parametrize("ntaps,ch", [(102, 300), (256, 37), (512, 64), (16, 5)])
+def test_fir_q15_stage_at_block_cadence(ctx, orc, monkeypatch, ntaps, ch):
+    """`arm_fir_fast_q15(&FIR_I, I_buffer, I_FIR_out, AUDIO_BLOCK_SAMPLES)` (Minimal-SDR.ino:574-575) on a batch of channels: calls of 32 ..
+    512 samples take chain_q15mb_kernel's FIR-stage flavour (channel-batched tiles, the next history written by the same kernel), calls of
+    other lengths in between take the long-call kernel -- one history format, every hand-over exact.  Bit-exact against the oracle (pinned to
+    the compiled reference) and against the same stream through the long-call kernel alone (MSDR_NO_BLOCK=1); full-scale and -32768 rows."""
+    rng = np.random.default_rng(ntaps + ch)
+    taps = rng.integers(-2500, 2501, ntaps).astype(np.int16)
+    taps[::7] = 32639
+    taps[3::11] = -32768
+    plan = [128] * 20 + [64] * 4 + [512, 1000, 7] + [128] * 8 + [32] * 8 + [256, 130] + [128] * 6
+    n = sum(plan)
+    x = rng.integers(-32768, 32768, (ch, n)).astype(np.int16)
+    x[min(2, ch - 1)] = -32768
+    outs = []
+    for no_block in (False, True):
+        if no_block:
+            monkeypatch.setenv("MSDR_NO_BLOCK", "1")
+        else:
+            monkeypatch.delenv("MSDR_NO_BLOCK", raising=False)
+        fir = msdr.FirQ15(ctx, taps, ch)
+        got = np.empty_like(x)
+        o = 0
+        for m in plan:
+            dx, dy = ctx.to_device(np.ascontiguousarray(x[:, o:o + m])), ctx.array((ch, m), np.int16)
+            fir.process(dx, dy, m)
+            got[:, o:o + m] = dy.download()
+            o += m
+        outs.append(got)
+        fir.close()
+    monkeypatch.delenv("MSDR_NO_BLOCK", raising=False)
+    assert np.array_equal(outs[0], outs[1])
+    for c in sorted(set([0, 1, min(2, ch - 1), ch // 2, ch - 1])):
+        rc, want = orc.fir_q15_blocks(taps, np.concatenate([x[c], np.zeros((-n) % 128, np.int16)]), 128)
+        assert rc == 0 and np.array_equal(outs[0][c], want[:n]), (ntaps, c)

@@ -220,6 +220,20 @@ extern "C" int msdr_memcpy_d2h(msdr_ctx *ctx, void *dst, const void *d_src, size
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }
+// Not part of the C ABI (msdr_cmsis.cpp's host-array binding): a pinned host buffer the device reads and writes in place -- the shim's block
+// batch then needs no copy command on either side of the kernel, only the stream synchronisation CMSIS semantics ask for anyway.
+__attribute__((visibility("hidden"))) int msdr_mapped_alloc(msdr_ctx *ctx, size_t bytes, void **host, void **dev)
+{
+    if (int rc = bind(ctx)) return rc;
+    *host = nullptr; *dev = nullptr;
+    if (hipHostMalloc(host, bytes, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return fail(MSDR_STATUS_OUT_OF_MEMORY, "hipHostMalloc(%zu) failed", bytes); }
+    if (hipHostGetDevicePointer(dev, *host, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(*host); *host = nullptr; return fail(MSDR_STATUS_HIP_ERROR, "hipHostGetDevicePointer failed"); }
+    return 0;
+}
+__attribute__((visibility("hidden"))) void msdr_mapped_free(msdr_ctx *ctx, void *host)
+{
+    if (host && bind(ctx) == 0) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(host); }
+}
 extern "C" int msdr_memcpy_d2d(msdr_ctx *ctx, void *d_dst, const void *d_src, size_t bytes)
 {
     if (int rc = bind(ctx)) return rc;

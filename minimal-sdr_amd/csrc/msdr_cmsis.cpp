@@ -6,6 +6,10 @@
 #include <unordered_map>
 #include <vector>
 
+// msdr_api.hip (not part of the C ABI): a pinned host buffer mapped into the device's address space
+int msdr_mapped_alloc(msdr_ctx *ctx, size_t bytes, void **host, void **dev);
+void msdr_mapped_free(msdr_ctx *ctx, void *host);
+
 namespace {
 
 // kind: 0 fir q15, 1 fir f32, 2 biquad df1 f32.  coef: the bytes of pCoeffs the device tables were last built from -- CMSIS reads
@@ -19,9 +23,12 @@ struct Binding {
     uint32_t channels = 0;
     std::unordered_map<const void *, Entry> inst;  // keyed by the caller's instance struct, as CMSIS identifies a filter
     // msdr_cmsis_bind_host: pSrc / pDst are HOST arrays (the sketch's stack buffers, Minimal-SDR.ino:525-526, 574-575), staged through two
-    // device buffers that grow with the largest block seen
+    // PINNED host buffers the device reads and writes in place (they grow with the largest block seen): a call is memcpy in, the kernel,
+    // one stream synchronisation, memcpy out -- no copy command on the stream (two of them, each with a synchronisation of its own, were
+    // 37 of the 41 us of a 128-sample call)
     bool host = false;
-    void *d_in = nullptr, *d_out = nullptr;
+    void *h_in = nullptr, *h_out = nullptr;      // host addresses
+    void *d_in = nullptr, *d_out = nullptr;      // the same buffers as the device sees them
     size_t cap = 0;
 };
 Binding &binding() { static Binding b; return b; }
@@ -69,11 +76,12 @@ void follow_coeffs(Entry *e, const void *pCoeffs, Set &&set)
 }
 void drop_staging(Binding &b)
 {
-    if (b.ctx) { if (b.d_in) msdr_free(b.ctx, b.d_in); if (b.d_out) msdr_free(b.ctx, b.d_out); }
-    b.d_in = b.d_out = nullptr; b.cap = 0;
+    if (b.ctx) { msdr_mapped_free(b.ctx, b.h_in); msdr_mapped_free(b.ctx, b.h_out); }
+    b.h_in = b.h_out = b.d_in = b.d_out = nullptr; b.cap = 0;
 }
-// host-array binding: the block batch [channels][blockSize] of `esz`-byte samples goes host -> device -> `run` -> device -> host; the
-// call returns when pDst holds the result, as the CMSIS function does.  Device-pointer binding: `run` on the caller's pointers.
+// host-array binding: the block batch [channels][blockSize] of `esz`-byte samples goes into the pinned input buffer, `run` reads it and writes
+// the pinned output buffer over PCIe, and the call returns when pDst holds the result, as the CMSIS function does.  Device-pointer binding:
+// `run` on the caller's pointers.
 template <typename Run>
 void with_buffers(Binding &b, const void *pSrc, void *pDst, uint32_t blockSize, size_t esz, Run &&run)
 {
@@ -82,12 +90,13 @@ void with_buffers(Binding &b, const void *pSrc, void *pDst, uint32_t blockSize, 
     if (bytes == 0 || !pSrc || !pDst) return;
     if (bytes > b.cap) {
         drop_staging(b);
-        if (msdr_malloc(b.ctx, bytes, &b.d_in) != 0 || msdr_malloc(b.ctx, bytes, &b.d_out) != 0) { drop_staging(b); return; }
+        if (msdr_mapped_alloc(b.ctx, bytes, &b.h_in, &b.d_in) != 0 || msdr_mapped_alloc(b.ctx, bytes, &b.h_out, &b.d_out) != 0) { drop_staging(b); return; }
         b.cap = bytes;
     }
-    if (msdr_memcpy_h2d(b.ctx, b.d_in, pSrc, bytes) != 0) return;
+    memcpy(b.h_in, pSrc, bytes);
     if (run(b.d_in, b.d_out) != 0) return;
-    (void)msdr_memcpy_d2h(b.ctx, pDst, b.d_out, bytes);
+    if (msdr_ctx_synchronize(b.ctx) != 0) return;
+    memcpy(pDst, b.h_out, bytes);
 }
 
 }  // namespace

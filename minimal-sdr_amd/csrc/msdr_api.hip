@@ -3079,7 +3079,7 @@ __global__ void f32_to_q15_kernel(const float *__restrict__ src, short *__restri
 // tables first, envelope tables after: two launches of two kernels); a workgroup's record = {key, 0, 0, 0} | nw waves x tpw tiles of ONE key, a
 // group's tiles dealt round-robin to the waves, idle slots = -1.  Cached per (modes, n).
 static int chain_block_tiles(msdr_chain *c, int n_, const std::function<int(uint32_t)> &part_of, const std::function<int(uint32_t)> &key_of,
-                             const std::function<size_t(int, int)> &lds_of)
+                             const std::function<size_t(int, int)> &lds_of, int prefer_nw = 0)
 {
     if (c->btiles_mode_gen == c->mode_gen && c->btiles_n == (long long)n_) return 0;
     const int cpt = mb_cpt(n_);
@@ -3128,7 +3128,9 @@ static int chain_block_tiles(msdr_chain *c, int n_, const std::function<int(uint
             // time of a workgroup ~ tiles per wave x what its fullest SIMD carries: a second wave on a SIMD fills the first one's
             // waits (two tiles in ~1.5 x the time of one: profiles/r05/mfb_nw_sweep.txt)
             const long long cost = tpw * (w <= 4 ? 2 : 3);
-            if (best_cost < 0 || cost < best_cost) { best_cost = cost; bp.nw = (uint32_t)w; bp.tpw = (uint32_t)tpw; }
+            // (prefer_nw: among equal costs, at least that many waves -- a Q15 chain whose biquad nodes can run as the kernel's second phase
+            //  needs three waves per workgroup for it, also where one would do for the tiles: the single receiver)
+            if (best_cost < 0 || cost < best_cost || (cost == best_cost && (int)bp.nw < prefer_nw && w <= prefer_nw)) { best_cost = cost; bp.nw = (uint32_t)w; bp.tpw = (uint32_t)tpw; }
         }
         if (bp.nw == 0 || bp.tpw == 0) { bp.nw = 1; bp.tpw = 1; }
         const size_t per_wg = (size_t)bp.nw * bp.tpw;
@@ -3319,7 +3321,8 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     } else if (use_qb) {
         if (int rc = chain_block_tiles(c, (int)n_samples, [&](uint32_t ch) { const int m = c->h_mode[ch]; return (m == MSDR_MODE_LSB || m == MSDR_MODE_USB) ? 0 : 1; },
                                        [&](uint32_t ch) { return c->h_tapset[ch]; },
-                                       [&](int w, int tpw) { return qb_lds_bytes(c->qm_halo, (int)n_samples, c->qm_bsteps, w, tpw); })) return rc;
+                                       [&](int w, int tpw) { return qb_lds_bytes(c->qm_halo, (int)n_samples, c->qm_bsteps, w, tpw); },
+                                       (c->nnodes == 2 && c->nodes[0]->max_stage == 0 && c->nodes[1]->max_stage == 0 && n_samples == 128 && !c->no_fuse) ? 3 : 0)) return rc;
         nseg = 1; p.nseg = 1; p.warm = 0;
     } else
     if (use_mfw) {
@@ -3550,17 +3553,19 @@ extern "C" int msdr_chain_process(msdr_chain *c, const int16_t *d_if, void *d_au
     if (c->nnodes == 2 && !nodes_fused) {      // biquad1_dac -> biquad2_dac in one pass over the audio
         const bool slabs = (c->channels & 63u) == 0 && (n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0;
         const int per_group = c->nodes[0]->pipe_ch ? c->nodes[0]->pipe_ch : 64;
+        // one 128-sample block, the reference's cadence, one stage per node: the pipeline over sub-slabs inside the block (biquad_teensy_blk_kernel),
+        // ANY channel count -- the reference's own single receiver included (1 channel: 27 -> 12 us per tick; its rows past the end idle) --
+        // while its 16-channel workgroups find a CU each (4096 channels: 15.1 -> 13.2 us per tick; at 8192 the slab kernel is ahead again,
+        // 16.6 vs 17.3, tools/r05_nodes_x.sh); MSDR_BIQUAD_BLK=0 / 1 at create time overrides
+        const uint32_t blk_wgs = (c->channels + kTqbCh - 1) / kTqbCh;
+        if (n_samples == 128 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 && c->nodes[0]->max_stage == 0 && c->nodes[1]->max_stage == 0 &&
+            (c->blk_force >= 1 || (c->blk_force < 0 && blk_wgs <= (uint32_t)c->ctx->num_cus)))
+            hipLaunchKernelGGL(biquad_teensy_blk_kernel, dim3(blk_wgs), dim3(kTqbThreads), tqb_lds_bytes(), c->ctx->stream, (short *)d_audio,
+                               c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels);
+        else
         if ((n_samples & 127u) == 0 && (reinterpret_cast<uintptr_t>(d_audio) & 15) == 0 && c->channels % (unsigned)per_group == 0 &&
             c->nodes[0]->max_stage == 0 && c->nodes[1]->max_stage == 0) {
             // one stage per node (the reference's configuration): the recursions alone on two waves, the input products element-wise on the others
-            // (one 128-sample block, the reference's cadence: the pipeline over sub-slabs inside the block, while its 16-channel workgroups find a
-            //  CU each -- 4096 channels: 15.1 -> 13.2 us per tick; at 8192 the slab kernel is ahead again, 16.6 vs 17.3, tools/r05_nodes_x.sh;
-            //  MSDR_BIQUAD_BLK=0 / 1 at create time overrides)
-            const int blk_force = c->blk_force;
-            if (n_samples == 128 && (c->channels & 15u) == 0 && (blk_force == 1 || (blk_force < 0 && c->channels / kTqbCh <= (uint32_t)c->ctx->num_cus)))
-                hipLaunchKernelGGL(biquad_teensy_blk_kernel, dim3(c->channels / kTqbCh), dim3(kTqbThreads), tqb_lds_bytes(), c->ctx->stream, (short *)d_audio,
-                                   c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels);
-            else
             if (per_group == 64)
                 hipLaunchKernelGGL((biquad_teensy_pipe4_kernel<2, 64>), dim3(c->channels / 64), dim3(tq4_threads(64)), tq4_lds_bytes(64), c->ctx->stream, (short *)d_audio,
                                    c->nodes[0]->d_defs, c->nodes[1]->d_defs, (int)c->channels, (long long)n_samples);

@@ -83,7 +83,7 @@ def compact_record(rec):
     c = {"Msps": rec.get("value"), "ms_per_step": rec.get("ms_per_step"), "kernel_ms": r.get("kernel_ms"), "frac": r.get("frac"),
          "bound": r.get("bound"), "sclk_mhz": r.get("sclk_mhz"), "power_w": r.get("power_w"),
          {"rel_rms_worst": "parity", "mismatching_samples": "parity_mismatches", "max_abs_lsb": "parity_max_lsb"}[pkey]: par.get(pkey),
-         "kernel": str(rec.get("config", {}).get("kernel", ""))[:48]}
+         "kernel": str(rec.get("config", {}).get("kernel", ""))[:40]}
     for k in ("binding_frac", "mfma_frac_of_sustained", "step_ms", "node_pass_ms", "traffic", "tick_us", "launches_per_step", "graph_tick_us"):
         if r.get(k) is not None:
             c[k] = r[k]
@@ -1053,8 +1053,9 @@ def bench_chain(args, name, torch, msdr, ctx, dev, rank, world, dist, do_cpu, do
                    "biquad_stages": int(len(wl["bq"])), "in": "int16", "out": "int16" if (q15 or i16) else "fp32", "sharding": "independent channels per GPU, no data-path collective",
                    "kernel": info["kernel"], "grid": info["grid"], "time_segments": info["time_segments"], "iir_warmup": info["warmup"],
                    "tap_folding": not args.no_fold},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        # (four decimals, or -- a single receiver moves 47 MB/s -- two significant digits)
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved >= 1.0 else float("%.2g" % achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved / HBM_PEAK_GBS >= 1e-3 else float("%.2g" % (achieved / HBM_PEAK_GBS)), "traffic": None,
                      "kernel_ms": round(k_ms, 4), "launches_timed": int(launches),
                      "valu_tflops_executed": round(flop_exec * samples_per_step / (k_ms * 1e-3) / 1e12, 2),
                      "valu_frac_executed": round(flop_exec * samples_per_step / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4),
@@ -1357,10 +1358,12 @@ def main():
             # counts; `tick_us` = wall time per call with the calls queued back to back.  200 timed steps at least (a tick is ~10-20 us).
             keep_steps, keep_samples = args.steps, args.samples
             args.steps, args.samples = max(args.steps, 200), 128
-            for name, wl_name, q in (("c3_b128", "c3", False), ("c4_b128", "c4", False), ("q15_c3_b128", "c3", True)):
-                args.arith, args.named_record = ("q15" if q else "f32"), name
+            # (q15_c1_b128: the reference's OWN size -- one receiver -- as the reference writes it: Q15, both biquad nodes)
+            keep_channels = args.channels
+            for name, wl_name, q, chs in (("c3_b128", "c3", False, 0), ("c4_b128", "c4", False, 0), ("q15_c3_b128", "c3", True, 0), ("q15_c1_b128", "c3", True, 1)):
+                args.arith, args.named_record, args.channels = ("q15" if q else "f32"), name, (chs or keep_channels)
                 also[name] = bench_chain(args, wl_name, torch, msdr, ctx, dev, rank, world, dist, False, False)
-                args.named_record = None
+                args.named_record, args.channels = None, keep_channels
                 if also[name] is not None:
                     also[name]["warmup_steps_run"] = args.warmup_steps_run
                     also[name]["config"]["steps_timed"] = args.steps
@@ -1373,7 +1376,7 @@ def main():
                 for drop in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "data"):
                     rec.pop(drop, None)
             out["also"] = also
-            out["config"]["records"] = "headline = c3 (BASELINE.json configs[2]); also: fir (256-tap fp32 FIR stage alone), c2, c4, c5, q15_c3 (c3 through the reference's own integer arithmetic, bit-exact), c3_i16, and the 128-sample block cadence c3_b128 / c4_b128 / q15_c3_b128 -- each timed over the same K steps; their warm-up is W steps plus 0.2 s of untimed steps (warmup_steps_run), so that short steps are not timed on a card still climbing from its idle clock"
+            out["config"]["records"] = "headline = c3 (BASELINE.json configs[2]); also: fir (256-tap fp32 FIR stage alone), c2, c4, c5, q15_c3 (c3 through the reference's own integer arithmetic, bit-exact), c3_i16, and the 128-sample block cadence c3_b128 / c4_b128 / q15_c3_b128 / q15_c1_b128 (ONE receiver) -- each timed over the same K steps; their warm-up is W steps plus 0.2 s of untimed steps (warmup_steps_run), so that short steps are not timed on a card still climbing from its idle clock"
     if rank == 0:
         import ctypes as C
         ctx.lib.msdr_build_rev.restype = C.c_char_p

@@ -26,7 +26,7 @@ def test_two_rank_rehearsal_prints_one_complete_line():
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and len(d["rank_devices"]) == 2 and d["scaling"] == "weak"
     assert len(lines[0]) < 6000                                  # the driver keeps a log tail: the whole line must fit in it
     recs = d["roofline"]["records"]                              # compact summaries of the sub-records, inside the top-level roofline
-    assert {"fir", "fir512", "c2", "c4", "c5", "q15_c3", "c3_i16", "c3_b128", "c4_b128", "q15_c3_b128", "update_all"} <= set(recs)
+    assert {"fir", "fir512", "c2", "c4", "c5", "q15_c3", "c3_i16", "c3_b128", "c4_b128", "q15_c3_b128", "q15_c1_b128", "update_all"} <= set(recs)
     assert d["library_rev"]
     assert d["roofline"]["frac"] > 0 and d["parity"] is not None
     for name, rec in recs.items():

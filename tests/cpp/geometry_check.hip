@@ -40,6 +40,20 @@ int main()
             CHECK(2 * (u0 - s) + 16 <= cs, "H %d lane %d: entry %d past the copy (%d bytes)", H, lane, u0 - s + 7, cs);
         }
     }
+    // ---- the full-rate layout with the compact B operand keeps long filters on the matrix cores: two filters' copies beside at least two waves'
+    // windows in 160 KB for every tap count the tests claim (the host refuses the layout below two waves per workgroup) ----
+    for (int taps = 128; taps <= 1021; taps++)
+        for (int S = 0; S <= 2; S++) {
+            const int H = mf_halo(taps + 2 * S);
+            const int bsteps = (2 * 16 * mw_compact_stride(H) + 2047) / 2048;
+            int w = 0;
+            while (w < 16 && mw_lds_bytes(H, bsteps, w + 1, true) <= 160 * 1024) w++;
+            CHECK(w >= 2, "taps %d sections %d: %d waves fit", taps, S, w);
+            if (taps <= 516) CHECK(w >= 6, "taps %d sections %d: %d waves fit (six at 512 taps: profiles/r05/nco_long_taps.txt)", taps, S, w);
+            // (the k-step fragments of the same filters: 2 KB per 16 window samples and filter)
+            const int frag_steps = 2 * ((H + 32) / 16);
+            if (taps >= 512) CHECK(mw_lds_bytes(H, frag_steps, 2, true) > 160 * 1024, "taps %d: the fragment layout would fit two waves after all", taps);
+        }
     // ---- block-cadence geometry (msdr_chain_mfb.hiph): tiles of 32 rows = CPT channels x RPC rows for every block length the host accepts ----
     for (int n : {32, 64, 128, 256, 512}) {
         CHECK(mb_n_ok(n), "n %d", n);
